@@ -1,0 +1,385 @@
+/*
+ * flex_oracle.c -- CPU restatement of the reference's SpMM hot path.
+ * TEST INFRASTRUCTURE ONLY (see flex_oracle.h).  Build: oracle/Makefile
+ * (gcc -O3 -ffp-contract=off: the reference's CPU loop is host code of a .cu
+ * compiled by g++ -O3 without -march, i.e. separately rounded mul and add).
+ */
+#define _GNU_SOURCE
+#include "flex_oracle.h"
+#include <errno.h>
+#include <float.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ ingest */
+
+static char *read_file(const char *path, size_t *len) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return NULL;
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    char *buf = (char *)malloc((size_t)sz + 2);
+    if (!buf) { fclose(f); return NULL; }
+    size_t got = fread(buf, 1, (size_t)sz, f);
+    fclose(f);
+    buf[got] = '\n';
+    buf[got + 1] = 0;
+    *len = got;
+    return buf;
+}
+
+/* Count comma-separated tokens of one line the way
+ * `while(getline(ss,word,','))` does (DataLoader.cu:21-23): a trailing comma
+ * produces no extra token. */
+static size_t count_tokens(const char *b, const char *e) {
+    if (b == e) return 0;
+    size_t n = 1;
+    for (const char *p = b; p < e; ++p)
+        if (*p == ',') ++n;
+    if (e[-1] == ',') --n;
+    return n;
+}
+
+static const char *basename_of(const char *path) {
+    const char *s = strrchr(path, '/');
+    return s ? s + 1 : path;
+}
+
+/* classes by file name, DataLoader.cu:62-84 */
+static int classes_for(const char *name) {
+    static const struct { const char *n; int c; } tab[] = {
+        {"polblogs.csv", 2}, {"cora.csv", 7},   {"citeseer.csv", 6}, {"pubmed.csv", 3},
+        {"ppi.csv", 121},    {"reddit.csv", 41}, {"flickr.csv", 7},  {"yelp.csv", 100},
+        {"amazon.csv", 107}};
+    for (size_t i = 0; i < sizeof tab / sizeof tab[0]; ++i)
+        if (!strcmp(name, tab[i].n)) return tab[i].c;
+    return 100;
+}
+
+static int cmp_u32(const void *a, const void *b) {
+    uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+    return (x > y) - (x < y);
+}
+
+/* graph statistics, DataLoader.cu:86-115, without the vector<map> (same results:
+ * e_inv[dst] is the set of sources of dst, i.e. row dst of the transpose). */
+static int graph_stats(oracle_csr *a) {
+    const int64_t m = a->m, nnz = a->nnz;
+    uint32_t *tp = (uint32_t *)calloc((size_t)m + 1, sizeof(uint32_t));
+    uint32_t *tsrc = (uint32_t *)malloc((size_t)(nnz ? nnz : 1) * sizeof(uint32_t));
+    float *tval = (float *)malloc((size_t)(nnz ? nnz : 1) * sizeof(float));
+    uint32_t *fill = (uint32_t *)calloc((size_t)m + 1, sizeof(uint32_t));
+    if (!tp || !tsrc || !tval || !fill) return -ENOMEM;
+    for (int64_t e = 0; e < nnz; ++e) {
+        if (a->col[e] >= (uint32_t)m) return -EDOM;
+        tp[a->col[e] + 1]++;
+    }
+    for (int64_t r = 0; r < m; ++r) tp[r + 1] += tp[r];
+    for (int64_t r = 0; r < m; ++r)
+        for (uint32_t e = a->rowPtr[r]; e < a->rowPtr[r + 1]; ++e) {
+            uint32_t d = a->col[e];
+            uint32_t pos = tp[d] + fill[d]++;
+            tsrc[pos] = (uint32_t)r; /* ascending r within each d by construction */
+            tval[pos] = a->vals[e];
+        }
+    /* assert( e_inv[dst].count(r) == 0 ): duplicate (r,dst) */
+    for (int64_t d = 0; d < m; ++d)
+        for (uint32_t p = tp[d] + 1; p < tp[d + 1]; ++p)
+            if (tsrc[p] == tsrc[p - 1]) return -EEXIST;
+    a->n_edges_one_way = a->n_edges_asymmetric = 0;
+    for (int64_t r = 0; r < m; ++r)
+        for (uint32_t e = a->rowPtr[r]; e < a->rowPtr[r + 1]; ++e) {
+            /* e_inv[r].count(col[e]): is there an edge col[e] -> r */
+            uint32_t key = a->col[e];
+            uint32_t lo = tp[r], hi = tp[r + 1];
+            uint32_t *hit = (uint32_t *)bsearch(&key, tsrc + lo, hi - lo, sizeof(uint32_t), cmp_u32);
+            if (!hit) a->n_edges_one_way++;
+            else if (tval[hit - tsrc] != a->vals[e]) a->n_edges_asymmetric++;
+        }
+    a->n_nodes_z_out = a->n_nodes_z_in = a->n_nodes_z_deg = 0;
+    for (int64_t r = 0; r < m; ++r) {
+        int z_out = a->rowPtr[r] == a->rowPtr[r + 1];
+        int z_in = tp[r] == tp[r + 1];
+        a->n_nodes_z_out += z_out;
+        a->n_nodes_z_in += z_in;
+        a->n_nodes_z_deg += (z_in && z_out);
+    }
+    a->is_directed = a->n_edges_one_way != 0;
+    free(tp); free(tsrc); free(tval); free(fill);
+    return 0;
+}
+
+int oracle_csv_load(const char *path, oracle_csr *out, int rand_state_reset) {
+    memset(out, 0, sizeof *out);
+    if (rand_state_reset) srand(1);
+    size_t len = 0;
+    char *buf = read_file(path, &len);
+    if (!buf) return -ENOENT;
+    const char *name = basename_of(path);
+    /* three lines: rowPtr, col, vals (DataLoader.cu:19-54) */
+    const char *lb[3] = {0, 0, 0}, *le[3] = {0, 0, 0};
+    const char *p = buf, *end = buf + len;
+    for (int i = 0; i < 3 && p <= end; ++i) {
+        const char *q = memchr(p, '\n', (size_t)(end - p) + 1);
+        lb[i] = p;
+        le[i] = q;
+        while (le[i] > lb[i] && (le[i][-1] == '\r')) --le[i];
+        p = q + 1;
+        if (p > end) break;
+    }
+    if (!lb[0] || !lb[1]) { free(buf); return -EINVAL; }
+    size_t n_rp = count_tokens(lb[0], le[0]);
+    size_t n_col = count_tokens(lb[1], le[1]);
+    if (n_rp < 1) { free(buf); return -EINVAL; }
+    out->rowPtr = (uint32_t *)malloc(n_rp * sizeof(uint32_t));
+    out->col = (uint32_t *)malloc((n_col ? n_col : 1) * sizeof(uint32_t));
+    out->vals = (float *)malloc((n_col ? n_col : 1) * sizeof(float));
+    if (!out->rowPtr || !out->col || !out->vals) { free(buf); return -ENOMEM; }
+    char *q;
+    p = lb[0];
+    for (size_t i = 0; i < n_rp; ++i) { /* std::stoi */
+        out->rowPtr[i] = (uint32_t)strtol(p, &q, 10);
+        if (q == p) { free(buf); return -EINVAL; }
+        p = q + 1;
+    }
+    out->uni_nb = 0; /* DataLoader.cu:26-29 */
+    for (size_t i = 1; i < n_rp; ++i)
+        if (out->rowPtr[i] - out->rowPtr[i - 1] == 1) out->uni_nb++;
+    p = lb[1];
+    for (size_t i = 0; i < n_col; ++i) {
+        out->col[i] = (uint32_t)strtol(p, &q, 10);
+        if (q == p) { free(buf); return -EINVAL; }
+        p = q + 1;
+    }
+    if (!strcmp(name, "amazon.csv")) { /* DataLoader.cu:36-46 */
+        for (size_t i = 0; i < n_col; ++i)
+            out->vals[i] = 2 * (float)rand() / (float)RAND_MAX - 1.0f;
+    } else {
+        size_t n_val = lb[2] ? count_tokens(lb[2], le[2]) : 0;
+        if (n_val != n_col) { free(buf); return -ERANGE; } /* assert(col.size()==vals.size()) */
+        p = lb[2];
+        for (size_t i = 0; i < n_val; ++i) { /* std::stof */
+            out->vals[i] = strtof(p, &q);
+            if (q == p) { free(buf); return -EINVAL; }
+            p = q + 1;
+        }
+    }
+    free(buf);
+    out->m = out->n = (int64_t)n_rp - 1;
+    out->nnz = (int64_t)n_col;
+    if (out->rowPtr[out->m] != (uint32_t)out->nnz) return -ERANGE;
+    for (int64_t r = 0; r < out->m; ++r)
+        if (out->rowPtr[r] > out->rowPtr[r + 1]) return -ERANGE;
+    out->c = classes_for(name);
+    return graph_stats(out);
+}
+
+void oracle_csr_free(oracle_csr *a) {
+    free(a->rowPtr); free(a->col); free(a->vals);
+    memset(a, 0, sizeof *a);
+}
+
+/* ------------------------------------------------------------- B generator */
+
+void oracle_gen_B(int64_t n, int k, float *B, int rand_state_reset) {
+    if (rand_state_reset) srand(1);
+    for (int64_t i = 0; i < n; ++i)
+        for (int j = 0; j < k; ++j)
+            B[i * k + j] = 2 * (float)rand() / (float)RAND_MAX - 1.0f;
+}
+
+/* -------------------------------------------------------------------- SpMM */
+
+static void spmm_rows(int64_t r0, int64_t r1, const uint32_t *rowPtr, const uint32_t *col,
+                      const float *vals, const float *B, float *C, int k) {
+    for (int64_t r = r0; r < r1; ++r) {
+        float *c = C + r * k;
+        for (int j = 0; j < k; ++j) c[j] = 0.0f;
+        for (uint32_t e = rowPtr[r]; e < rowPtr[r + 1]; ++e) {
+            const float *b = B + (int64_t)k * col[e];
+            const float v = vals[e];
+            for (int j = 0; j < k; ++j) c[j] += b[j] * v;
+        }
+    }
+}
+
+void oracle_spmm(int64_t m, const uint32_t *rowPtr, const uint32_t *col, const float *vals,
+                 const float *B, float *C, int k) {
+    spmm_rows(0, m, rowPtr, col, vals, B, C, k);
+}
+
+typedef struct {
+    int64_t r0, r1;
+    const uint32_t *rowPtr, *col;
+    const float *vals, *B;
+    float *C;
+    int k;
+} mt_arg;
+
+static void *mt_run(void *p) {
+    mt_arg *a = (mt_arg *)p;
+    spmm_rows(a->r0, a->r1, a->rowPtr, a->col, a->vals, a->B, a->C, a->k);
+    return NULL;
+}
+
+void oracle_spmm_mt(int64_t m, const uint32_t *rowPtr, const uint32_t *col, const float *vals,
+                    const float *B, float *C, int k, int nthreads) {
+    if (nthreads <= 1 || m < nthreads) { oracle_spmm(m, rowPtr, col, vals, B, C, k); return; }
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    mt_arg *args = (mt_arg *)malloc(sizeof(mt_arg) * (size_t)nthreads);
+    /* nnz-balanced contiguous row chunks (cost = nnz + rows) */
+    const double total = (double)rowPtr[m] + (double)m;
+    int64_t r = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        int64_t r0 = r;
+        const double want = total * (t + 1) / nthreads;
+        while (r < m && (double)rowPtr[r + 1] + (double)(r + 1) <= want) ++r;
+        if (t == nthreads - 1) r = m;
+        args[t] = (mt_arg){r0, r, rowPtr, col, vals, B, C, k};
+        pthread_create(&th[t], NULL, mt_run, &args[t]);
+    }
+    for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+    free(th); free(args);
+}
+
+/* ---------------------------------------------------------------- resCheck */
+
+int64_t oracle_rescheck(const float *gold, const float *res, const uint32_t *orig_rowPtr,
+                        int64_t m, int k, double *max_err_out, int32_t *max_err_row_nnz,
+                        int64_t *gold_zeros) {
+    int64_t count = 0, nz = 0;
+    double max_err = 0;
+    int32_t me_nnz = 0;
+    for (int64_t r = 0; r < m; ++r) {
+        const int row_nnz = (int)(orig_rowPtr[r + 1] - orig_rowPtr[r]);
+        const double tol = (double)FLT_EPSILON * row_nnz * 4; /* flex.cu:4172 */
+        for (int c = 0; c < k; ++c) {
+            const int64_t idx = r * k + c;
+            if (gold[idx] == 0) nz++;
+            const double err = fabsf(gold[idx]) < 1
+                                   ? fabs((double)gold[idx] - res[idx])
+                                   : fabs(1.0 - (double)res[idx] / gold[idx]);
+            if (err > max_err) { max_err = err; me_nnz = row_nnz; }
+            if (err > tol) count++;
+            /* NaN never compares > tol in the reference either; flag it here so a
+             * NaN-producing kernel cannot slip through the checker. */
+            if (err != err) count++;
+        }
+    }
+    if (max_err_out) *max_err_out = max_err;
+    if (max_err_row_nnz) *max_err_row_nnz = me_nnz;
+    if (gold_zeros) *gold_zeros = nz;
+    return count;
+}
+
+/* --------------------------------------------------------------------- RCM */
+
+typedef struct { uint64_t key, val; } keyval;
+
+static int cmp_deg_asc(const void *a, const void *b) { /* order_deg.cu:9-11 */
+    const keyval *x = (const keyval *)a, *y = (const keyval *)b;
+    if (x->val != y->val) return x->val < y->val ? -1 : 1;
+    return (x->key > y->key) - (x->key < y->key);
+}
+
+static int cmp_u64(const void *a, const void *b) {
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return (x > y) - (x < y);
+}
+
+int oracle_order_rcm(int64_t n, const uint32_t *rowPtr, const uint32_t *col, uint64_t *rank) {
+    const int64_t e = rowPtr[n];
+    /* Edgelist(dl): edges (i, col[j]) in CSR order, edgelist.cu:23-32.
+     * compute_degrees: deg = degIn + degOut, edgelist.cu:86-103. */
+    uint64_t *degOut = (uint64_t *)calloc((size_t)n + 1, sizeof(uint64_t));
+    uint64_t *degIn = (uint64_t *)calloc((size_t)n + 1, sizeof(uint64_t));
+    keyval *ts = (keyval *)malloc(sizeof(keyval) * (size_t)(n ? n : 1));
+    uint64_t *rank_deg = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n ? n : 1));
+    uint64_t *cd = (uint64_t *)calloc((size_t)n + 1, sizeof(uint64_t));
+    uint64_t *fill = (uint64_t *)calloc((size_t)n + 1, sizeof(uint64_t));
+    uint64_t *adj = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(e ? e : 1));
+    uint64_t *order = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n ? n : 1));
+    uint8_t *placed = (uint8_t *)calloc((size_t)n + 1, 1);
+    if (!degOut || !degIn || !ts || !rank_deg || !cd || !fill || !adj || !order || !placed)
+        return -ENOMEM;
+    for (int64_t i = 0; i < n; ++i)
+        for (uint32_t j = rowPtr[i]; j < rowPtr[i + 1]; ++j) {
+            degOut[i]++;
+            degIn[col[j]]++;
+        }
+    /* order_deg(h,false): rank by (deg ASC, node ASC), order_deg.cu:19-45 */
+    for (int64_t u = 0; u < n; ++u) ts[u] = (keyval){(uint64_t)u, degIn[u] + degOut[u]};
+    qsort(ts, (size_t)n, sizeof(keyval), cmp_deg_asc);
+    for (int64_t u = 0; u < n; ++u) rank_deg[ts[u].key] = (uint64_t)u;
+    /* Dadjlist g(h, rank_deg): out-adjacency in relabelled ids, neighbours sorted,
+     * adjlist.cu:62-73 (build_from_edgelist_ranked -> sorted=true), 127-150 */
+    for (int64_t u = 0; u < n; ++u) cd[rank_deg[u] + 1] = degOut[u];
+    for (int64_t u = 0; u < n; ++u) cd[u + 1] += cd[u];
+    for (int64_t i = 0; i < n; ++i) {
+        const uint64_t u = rank_deg[i];
+        for (uint32_t j = rowPtr[i]; j < rowPtr[i + 1]; ++j) adj[cd[u] + fill[u]++] = rank_deg[col[j]];
+    }
+    for (int64_t u = 0; u < n; ++u)
+        qsort(adj + cd[u], (size_t)(cd[u + 1] - cd[u]), sizeof(uint64_t), cmp_u64);
+    /* algo_bfs(g, 0): algo_bfs.cu:11-39 */
+    uint64_t head = 0, tail = 0;
+    for (int64_t c = 0; c < n; ++c) {
+        if (placed[c]) continue;
+        order[tail++] = (uint64_t)c;
+        placed[c] = 1;
+        while (head < tail) {
+            const uint64_t w = order[head++];
+            for (uint64_t a = cd[w]; a < cd[w + 1]; ++a) {
+                const uint64_t v = adj[a];
+                if (placed[v]) continue;
+                placed[v] = 1;
+                order[tail++] = v;
+            }
+        }
+    }
+    /* rank_from_order (tools.cu:31-43) then reverse + compose (order_rcm.cu:28-31);
+     * degOut is reused as rank_bfs */
+    uint64_t *rank_bfs = degOut;
+    for (int64_t i = 0; i < n; ++i) rank_bfs[order[i]] = (uint64_t)i;
+    for (int64_t u = 0; u < n; ++u) rank[u] = (uint64_t)n - 1 - rank_bfs[rank_deg[u]];
+    free(degOut); free(degIn); free(ts); free(rank_deg); free(cd); free(fill);
+    free(adj); free(order); free(placed);
+    return 0;
+}
+
+typedef struct { uint32_t dst; float val; } dstval;
+static int cmp_dst(const void *a, const void *b) {
+    const dstval *x = (const dstval *)a, *y = (const dstval *)b;
+    return (x->dst > y->dst) - (x->dst < y->dst);
+}
+
+void oracle_perm_csr(int64_t n, const uint32_t *rowPtr, const uint32_t *col, const float *vals,
+                     const uint64_t *rank, int32_t *vo_mp, uint32_t *rowPtr2, uint32_t *col2,
+                     float *vals2) {
+    for (int64_t u = 0; u < n; ++u) vo_mp[rank[u]] = (int32_t)u; /* DataLoader.cu:747-750 */
+    rowPtr2[0] = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t v = vo_mp[i];
+        rowPtr2[i + 1] = rowPtr2[i] + rowPtr[v + 1] - rowPtr[v];
+    }
+    uint32_t maxd = 0;
+    for (int64_t i = 0; i < n; ++i)
+        if (rowPtr[i + 1] - rowPtr[i] > maxd) maxd = rowPtr[i + 1] - rowPtr[i];
+    dstval *perm = (dstval *)malloc(sizeof(dstval) * (size_t)(maxd ? maxd : 1));
+    for (int64_t s = 0; s < n; ++s) { /* DataLoader.cu:758-779 */
+        const uint64_t s2 = rank[s];
+        const uint32_t d = rowPtr[s + 1] - rowPtr[s];
+        for (uint32_t i = 0; i < d; ++i)
+            perm[i] = (dstval){(uint32_t)rank[col[rowPtr[s] + i]], vals[rowPtr[s] + i]};
+        qsort(perm, d, sizeof(dstval), cmp_dst);
+        for (uint32_t i = 0; i < d; ++i) {
+            col2[rowPtr2[s2] + i] = perm[i].dst;
+            vals2[rowPtr2[s2] + i] = perm[i].val;
+        }
+    }
+    free(perm);
+}

@@ -1,0 +1,31 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return np.load(os.path.join(GOLDEN, "golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def pubmed():
+    import oracle
+    return oracle.csv_load(os.path.join(GOLDEN, "pubmed.csv"))
+
+
+@pytest.fixture(scope="session")
+def a_mat():
+    import oracle
+    return oracle.csv_load(os.path.join(GOLDEN, "a_mat.csv"))
