@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- SpMM GFLOPS (2*nnz*k/t) of the MI355X-native engine, one process per GPU.
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload flickr] [--k 128]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one flex_spmm() over the whole (sharded) matrix with A's plan and B resident
+in HBM.  N=1 workload: BASELINE.json configs[1], the Flickr shape (89250^2, 989006 nnz),
+k=128, fp32 -- a synthetic stand-in with exactly that n and nnz (the reference ships only
+pubmed.csv).  N>1: weak scaling -- the same generator at N x n vertices and N x nnz
+nonzeros, RCM-reordered, rows sharded over the ranks by flex_shard_rows, B broadcast once
+over RCCL (torch.distributed "nccl") before the timed region; no collective on the data path.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and
+`cpu_baseline` objects.  The oracle is used here only for the reported CPU baseline.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="flickr", help="synthetic preset: flickr|reddit|amazon|yelp|ppi|pubmed")
+    ap.add_argument("--k", type=int, default=128)
+    ap.add_argument("--order", default="rcm", choices=["rcm", "natural"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="verify rank 0's shard against the oracle (small workloads)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import flex_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: there is no CPU fallback for the measured path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    k = args.k
+    scale = world if args.scaling == "weak" else 1
+    # ---- workload: synthetic graph with the README's shape (x N vertices and nonzeros when weak-scaling)
+    n0, nnz0, alpha, comm, p_in, p_near, win, gcn = flex_amd.SYNTH_PRESETS[args.workload]
+    if (nnz0 - n0) % 2:
+        nnz0 -= 1
+    t_gen = time.perf_counter()
+    a = flex_amd.synth_graph(n=n0 * scale, nnz=nnz0 * scale, alpha=alpha, community=comm, p_in=p_in,
+                             p_near=p_near, near_window=win, gcn_norm=bool(gcn),
+                             seed=0xF1E0 + sorted(flex_amd.SYNTH_PRESETS).index(args.workload))
+    t_gen = time.perf_counter() - t_gen
+
+    # ---- plan: RCM is a schedule (N=1) or an explicit permutation followed by row sharding (N>1)
+    t_plan = time.perf_counter()
+    order = flex_amd.FLEX_ORDER_RCM if args.order == "rcm" else flex_amd.FLEX_ORDER_NATURAL
+    if world == 1:
+        plan = flex_amd.Plan(a, k, device=local_rank, order=order)
+        shard_nnz, shard_rows = a.nnz, a.m
+        a_local, vo, r0, r1 = a, None, 0, a.m
+    else:
+        if args.order == "rcm":
+            vo, a_local = flex_amd.perm_csr(a, flex_amd.order_rcm(a))
+        else:
+            vo, a_local = None, a
+        bounds = flex_amd.shard_rows(a_local, k, world)
+        r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+        plan = flex_amd.Plan(a_local, k, device=local_rank, rows=(r0, r1), col_map=vo)
+        shard_nnz = int(a_local.rowPtr[r1]) - int(a_local.rowPtr[r0])
+        shard_rows = r1 - r0
+    t_plan = time.perf_counter() - t_plan
+    info = plan.info()
+
+    # ---- B: generated on rank 0, broadcast once over RCCL/xGMI (untimed, reported)
+    dev = torch.device("cuda", local_rank)
+    if rank == 0:
+        g = torch.Generator(device=dev)
+        g.manual_seed(1)
+        B = torch.rand((a.n, k), generator=g, device=dev, dtype=torch.float32) * 2 - 1
+    else:
+        B = torch.empty((a.n, k), device=dev, dtype=torch.float32)
+    bcast_ms = 0.0
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        dist.broadcast(B, src=0)
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+    C = torch.empty((shard_rows, k), device=dev, dtype=torch.float32)
+    stream = torch.cuda.current_stream().cuda_stream
+    bp, cp = B.data_ptr(), C.data_ptr()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        plan.spmm(bp, cp, stream)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        plan.spmm(bp, cp, stream)
+    ev1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream (torch's current stream)
+    if world > 1:
+        t = torch.tensor([wall, dev_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall, dev_ms = float(t[0]), float(t[1])
+
+    ok = None
+    if args.check and rank == 0:
+        import oracle
+        Bh = B.cpu().numpy()
+        rp = a_local.rowPtr[r0:r1 + 1].astype(np.int64)
+        rp0 = rp - rp[0]
+        cols = a_local.col[rp[0]:rp[-1]]
+        if vo is not None:
+            cols = vo[cols].astype(np.uint32)
+        gold = oracle.spmm(rp0.astype(np.uint32), cols, a_local.vals[rp[0]:rp[-1]], Bh, nthreads=os.cpu_count() or 1)
+        cnt, max_err, _, _ = oracle.rescheck(gold, C.cpu().numpy(), rp0.astype(np.uint32))
+        ok = {"mismatches": cnt, "max_err": max_err}
+        if cnt:
+            raise SystemExit(f"bench --check: {cnt} mismatches vs oracle")
+
+    if rank == 0:
+        ms_per_step = wall * 1e3 / args.steps
+        flops = 2.0 * a.nnz * k  # all ranks together process every nonzero once per step
+        gflops = flops / (wall / args.steps) / 1e9
+        # roofline of the dominant kernel (spmm_v4_kernel): algorithmic bytes of ONE launch on this
+        # rank = rowPtr + (col,val) + B read once + C written once  (flex.cu:4672)
+        b_alg = 4.0 * (shard_rows + 1) + 8.0 * shard_nnz + 4.0 * a.n * k + 4.0 * shard_rows * k
+        kern_ms = dev_ms / args.steps
+        achieved = b_alg / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "SpMM GFLOPS (2*nnz*k/t)", "value": round(gflops, 2), "unit": "GFLOPS",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 6), "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}-shape synthetic graph x{scale} (n={a.n}, nnz={a.nnz}), k={k}, fp32, "
+                            f"{args.order} schedule" + (f", rows sharded over {world} GPUs, B broadcast once" if world > 1 else ""),
+                "n": a.n, "nnz": a.nnz, "k": k, "order": args.order, "parallelism": f"row-shard x{world}",
+                "plan": {"waves": info["n_waves"], "tasks": info["n_tasks"], "split_rows": info["n_split_rows"],
+                         "lanes_per_nz": info["lanes_per_nz"], "plan_s": round(t_plan, 3), "gen_s": round(t_gen, 3)},
+                "b_bcast_ms": round(bcast_ms, 3),
+            },
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(args, world),
+                         "kernel": "spmm_v4_kernel", "kernel_ms": round(kern_ms, 6),
+                         "algorithmic_bytes_per_launch": int(b_alg)},
+        }
+        if ok is not None:
+            out["check"] = ok
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a, k, B)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _pmc_traffic(args, world):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*.json), or null."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(p))
+        return d.get(f"{args.workload}_k{args.k}_{args.order}_n{world}")
+    except Exception:
+        return None
+
+
+def cpu_baseline(a, k, B):
+    """The reference's CPU SpMM arithmetic (oracle port of aspt/sspmm_128.cu:1415-1422) timed on this
+    host on a bounded sample of the same workload: the first rows holding <= ~3e9 flops."""
+    import oracle
+    cores = min(os.cpu_count() or 1, 16)
+    budget = 3.0e9 / (2.0 * k)  # nonzeros
+    rp = a.rowPtr.astype(np.int64)
+    rows = int(np.searchsorted(rp, budget, side="right")) - 1 if a.nnz > budget else a.m
+    rows = max(rows, 1)
+    nnz = int(rp[rows])
+    rp_s = a.rowPtr[: rows + 1]
+    Bh = B.cpu().numpy()
+    best1 = bestN = 1e30
+    for i in range(3):
+        t0 = time.perf_counter()
+        oracle.spmm(rp_s, a.col[:nnz], a.vals[:nnz], Bh, nthreads=cores)
+        bestN = min(bestN, time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    oracle.spmm(rp_s, a.col[:nnz], a.vals[:nnz], Bh, nthreads=1)
+    best1 = time.perf_counter() - t0
+    return {"value": round(2.0 * nnz * k / bestN / 1e9, 3), "unit": "GFLOPS", "cores": cores, "kind": "port",
+            "sample": f"first {rows} rows ({nnz} nnz) of the same graph and B, best of 3",
+            "single_thread_value": round(2.0 * nnz * k / best1 / 1e9, 3)}
+
+
+if __name__ == "__main__":
+    main()

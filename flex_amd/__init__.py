@@ -1,0 +1,26 @@
+"""flex_amd -- MI355X-native SpMM engine behind guohaoqiang/Flex's bench loop.
+
+The product is the C-ABI library ``flex_amd/lib/libflex_spmm.so`` (sources in
+``flex_amd/csrc``, declarations in ``include/flex_spmm.h``) plus the C++ host mirror
+of the reference's DataLoader/Mat/run interface (``flex_amd/csrc/host``).  This Python
+package is only the ctypes binding that tests and bench.py drive it through; it has
+no compute path of its own and raises if the HIP library is missing.
+"""
+from .binding import (  # noqa: F401
+    FLEX_ORDER_NATURAL,
+    FLEX_ORDER_RCM,
+    FlexError,
+    HostCsr,
+    Plan,
+    build,
+    csv_load,
+    fill_dense_rand,
+    gather_rows,
+    lib,
+    lib_path,
+    order_rcm,
+    perm_csr,
+    shard_rows,
+    synth_graph,
+    SYNTH_PRESETS,
+)

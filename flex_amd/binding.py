@@ -1,0 +1,289 @@
+"""ctypes binding of include/flex_spmm.h (the C ABI of libflex_spmm.so).
+
+Device buffers are raw pointers (``tensor.data_ptr()``), streams are raw hipStream_t
+values (``torch.cuda.current_stream().cuda_stream``): torch is plumbing here, the
+kernels live in the shared library.  There is no fallback: if the library is missing
+or a call fails, FlexError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+_SO = os.path.join(_HERE, "lib", "libflex_spmm.so")
+
+FLEX_ORDER_NATURAL = 0
+FLEX_ORDER_RCM = 1
+
+
+class FlexError(RuntimeError):
+    pass
+
+
+class _Csr(C.Structure):  # flex_csr
+    _fields_ = [("m", C.c_int32), ("n", C.c_int32), ("nnz", C.c_int64),
+                ("rowPtr", C.c_void_p), ("col", C.c_void_p), ("vals", C.c_void_p)]
+
+
+class _HostCsr(C.Structure):  # flex_host_csr
+    _fields_ = [("m", C.c_int32), ("n", C.c_int32), ("nnz", C.c_int64),
+                ("rowPtr", C.POINTER(C.c_uint32)), ("col", C.POINTER(C.c_uint32)),
+                ("vals", C.POINTER(C.c_float)),
+                ("uni_nb", C.c_int64), ("n_edges_one_way", C.c_int64),
+                ("n_edges_asymmetric", C.c_int64),
+                ("n_nodes_z_out", C.c_int32), ("n_nodes_z_in", C.c_int32),
+                ("n_nodes_z_deg", C.c_int32), ("is_directed", C.c_int32), ("c", C.c_int32)]
+
+
+class _PlanInfo(C.Structure):  # flex_plan_info
+    _fields_ = [("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("device", C.c_int32),
+                ("nnz", C.c_int64), ("n_tasks", C.c_int64), ("n_waves", C.c_int64),
+                ("n_split_rows", C.c_int64), ("n_partials", C.c_int64),
+                ("device_bytes", C.c_int64), ("lanes_per_nz", C.c_int32), ("order", C.c_int32),
+                ("plan_ms", C.c_double)]
+
+
+class _SynthParams(C.Structure):  # flex_synth_params
+    _fields_ = [("n", C.c_int64), ("nnz", C.c_int64), ("alpha", C.c_double),
+                ("community", C.c_int64), ("p_in", C.c_double), ("p_near", C.c_double),
+                ("near_window", C.c_int32), ("shuffle", C.c_int32), ("gcn_norm", C.c_int32),
+                ("seed", C.c_uint64)]
+
+
+# every symbol include/flex_spmm.h declares (tests/test_abi.py checks the header against this)
+SYMBOLS = [
+    "flex_plan_create", "flex_plan_create_mapped", "flex_plan_create_rows", "flex_spmm",
+    "flex_plan_destroy", "flex_plan_get_info", "flex_gather_rows", "flex_csv_load",
+    "flex_host_csr_free", "flex_fill_dense_rand", "flex_order_rcm", "flex_perm_csr",
+    "flex_shard_rows", "flex_synth_graph", "flex_strerror", "flex_last_hip_error",
+    "flex_last_hip_error_string", "flex_abi_version",
+]
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _SO
+
+
+def build(force: bool = False) -> str:
+    """Compile libflex_spmm.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    if force and os.path.exists(_SO):
+        os.remove(_SO)
+    subprocess.check_call(["make", "-s", "-C", _CSRC, "all"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise FlexError(f"{_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(there is no CPU fallback)")
+        # torch bundles its own libamdhip64.so; if ours were loaded first, libflex_spmm.so would bind
+        # to /opt/rocm's copy and the process would hold TWO HIP runtimes (the second one sees no
+        # device, and pointers/streams of one are foreign to the other).  Import torch first so the
+        # library resolves to the runtime that owns the tensors it is handed.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = C.CDLL(_SO)
+        vp, i64, i32, u32 = C.c_void_p, C.c_int64, C.c_int, C.c_uint
+        L.flex_plan_create.argtypes = [C.POINTER(vp), C.POINTER(_Csr), i32, i32, u32]
+        L.flex_plan_create_mapped.argtypes = [C.POINTER(vp), C.POINTER(_Csr), vp, i32, i32, u32]
+        L.flex_plan_create_rows.argtypes = [C.POINTER(vp), C.POINTER(_Csr), i64, i64, vp, i32, i32, u32]
+        L.flex_spmm.argtypes = [vp, vp, vp, vp]
+        L.flex_plan_destroy.argtypes = [vp]
+        L.flex_plan_get_info.argtypes = [vp, C.POINTER(_PlanInfo)]
+        L.flex_gather_rows.argtypes = [vp, vp, vp, i64, i32, vp]
+        L.flex_csv_load.argtypes = [C.c_char_p, C.POINTER(_HostCsr)]
+        L.flex_host_csr_free.argtypes = [C.POINTER(_HostCsr)]
+        L.flex_host_csr_free.restype = None
+        L.flex_fill_dense_rand.argtypes = [vp, i64, i32]
+        L.flex_order_rcm.argtypes = [C.POINTER(_Csr), vp]
+        L.flex_perm_csr.argtypes = [C.POINTER(_Csr), vp, vp, vp, vp, vp]
+        L.flex_shard_rows.argtypes = [C.POINTER(_Csr), i32, i32, vp]
+        L.flex_synth_graph.argtypes = [C.POINTER(_SynthParams), C.POINTER(_HostCsr)]
+        L.flex_strerror.argtypes = [i32]
+        L.flex_strerror.restype = C.c_char_p
+        L.flex_last_hip_error.restype = i32
+        L.flex_last_hip_error_string.restype = C.c_char_p
+        L.flex_abi_version.restype = i32
+        _lib = L
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        L = lib()
+        msg = L.flex_strerror(rc).decode()
+        if rc == -3:
+            msg += f" [hip {L.flex_last_hip_error()}: {L.flex_last_hip_error_string().decode()}]"
+        raise FlexError(f"{what}: {msg} ({rc})")
+
+
+class HostCsr:
+    """Host CSR (numpy, uint32 indices / float32 values) + the DataLoader statistics."""
+
+    def __init__(self, rowPtr, col, vals, n=None, **stats):
+        self.rowPtr = np.ascontiguousarray(rowPtr, dtype=np.uint32)
+        self.col = np.ascontiguousarray(col, dtype=np.uint32)
+        self.vals = np.ascontiguousarray(vals, dtype=np.float32)
+        self.m = len(self.rowPtr) - 1
+        self.n = self.m if n is None else int(n)
+        self.nnz = len(self.col)
+        self.__dict__.update(stats)
+
+    def view(self) -> _Csr:
+        return _Csr(self.m, self.n, self.nnz, self.rowPtr.ctypes.data, self.col.ctypes.data,
+                    self.vals.ctypes.data)
+
+
+def _take(s: _HostCsr) -> HostCsr:
+    n = s.n
+    try:
+        rp = np.ctypeslib.as_array(s.rowPtr, shape=(s.m + 1,)).copy()
+        col = np.ctypeslib.as_array(s.col, shape=(max(s.nnz, 1),))[: s.nnz].copy()
+        vals = np.ctypeslib.as_array(s.vals, shape=(max(s.nnz, 1),))[: s.nnz].copy()
+        stats = {k: getattr(s, k) for k in ("uni_nb", "n_edges_one_way", "n_edges_asymmetric",
+                                           "n_nodes_z_out", "n_nodes_z_in", "n_nodes_z_deg",
+                                           "is_directed", "c")}
+    finally:
+        lib().flex_host_csr_free(C.byref(s))
+    return HostCsr(rp, col, vals, n=n, **stats)
+
+
+def csv_load(path: str) -> HostCsr:
+    s = _HostCsr()
+    _check(lib().flex_csv_load(os.fsencode(path), C.byref(s)), f"flex_csv_load({path})")
+    return _take(s)
+
+
+def fill_dense_rand(n: int, k: int) -> np.ndarray:
+    B = np.empty((n, k), dtype=np.float32)
+    _check(lib().flex_fill_dense_rand(B.ctypes.data, n, k), "flex_fill_dense_rand")
+    return B
+
+
+def order_rcm(a: HostCsr) -> np.ndarray:
+    rank = np.empty(max(a.m, 1), dtype=np.uint32)
+    v = a.view()
+    _check(lib().flex_order_rcm(C.byref(v), rank.ctypes.data), "flex_order_rcm")
+    return rank[: a.m]
+
+
+def perm_csr(a: HostCsr, rank: np.ndarray):
+    """DataLoaderRcm body: returns (vo_mp, permuted HostCsr)."""
+    rank = np.ascontiguousarray(rank, dtype=np.uint32)
+    vo = np.empty(max(a.m, 1), dtype=np.int32)
+    rp2 = np.empty(a.m + 1, dtype=np.uint32)
+    c2 = np.empty(max(a.nnz, 1), dtype=np.uint32)
+    v2 = np.empty(max(a.nnz, 1), dtype=np.float32)
+    v = a.view()
+    _check(lib().flex_perm_csr(C.byref(v), rank.ctypes.data, vo.ctypes.data, rp2.ctypes.data,
+                               c2.ctypes.data, v2.ctypes.data), "flex_perm_csr")
+    return vo[: a.m], HostCsr(rp2, c2[: a.nnz], v2[: a.nnz], n=a.n)
+
+
+def shard_rows(a: HostCsr, k: int, nparts: int) -> np.ndarray:
+    bounds = np.empty(nparts + 1, dtype=np.int64)
+    v = a.view()
+    _check(lib().flex_shard_rows(C.byref(v), k, nparts, bounds.ctypes.data), "flex_shard_rows")
+    return bounds
+
+
+# Stand-ins for the graphs of README.md:13-20 (exact n and nnz; structure is synthetic).
+SYNTH_PRESETS = {
+    #            n         nnz        alpha community p_in p_near window gcn_norm
+    "pubmed": (19717, 108365 - 0, 2.6, 64, 0.6, 0.25, 8, 1),  # nnz-n must be even: adjusted below
+    "flickr": (89250, 989006, 2.3, 256, 0.55, 0.25, 8, 1),
+    "ppi": (14755, 458973 - 0, 2.4, 128, 0.6, 0.2, 8, 1),
+    "yelp": (716847, 13954819 - 0, 2.2, 512, 0.55, 0.25, 8, 1),
+    "reddit": (232965, 23446803, 2.1, 2048, 0.6, 0.25, 8, 1),
+    "amazon": (1569960, 264339468, 2.1, 4096, 0.6, 0.25, 8, 0),
+    # SuiteSparse stand-ins fetched by data/SuiteSparse/prepare_mtx_data.sh (shapes from SURVEY 8(d))
+    "wiki-vote": (8297, 103689 - 0, 2.2, 0, 0.0, 0.0, 8, 1),
+    "soc-sign-epinions": (131828, 841372, 2.2, 128, 0.4, 0.2, 8, 1),
+}
+
+
+def synth_graph(name: str | None = None, *, n=None, nnz=None, alpha=2.1, community=0, p_in=0.0,
+                p_near=0.0, near_window=8, shuffle=True, gcn_norm=True, seed=None) -> HostCsr:
+    if name is not None:
+        key = name.lower()
+        n, nnz, alpha, community, p_in, p_near, near_window, gcn = SYNTH_PRESETS[key]
+        gcn_norm = bool(gcn)
+        if (nnz - n) % 2:  # symmetric + one self loop per row needs nnz-n even
+            nnz -= 1
+        if seed is None:
+            seed = 0xF1E0 + sorted(SYNTH_PRESETS).index(key)
+    if seed is None:
+        seed = 0xF1E0
+    p = _SynthParams(int(n), int(nnz), float(alpha), int(community), float(p_in), float(p_near),
+                     int(near_window), int(bool(shuffle)), int(bool(gcn_norm)), int(seed))
+    s = _HostCsr()
+    _check(lib().flex_synth_graph(C.byref(p), C.byref(s)), f"flex_synth_graph({name or n})")
+    return _take(s)
+
+
+class Plan:
+    """flex_plan handle (≙ Mat after csr2_DiagTiling + alpha_transfer)."""
+
+    def __init__(self, a: HostCsr, k: int, device: int = 0, order: int = FLEX_ORDER_NATURAL,
+                 vo_mp=None, rows=None, col_map=None):
+        self._h = C.c_void_p()
+        self._keep = (a, vo_mp, col_map)
+        v = a.view()
+        L = lib()
+        if rows is not None:
+            cm = None if col_map is None else np.ascontiguousarray(col_map, dtype=np.int32)
+            self._keep = (a, cm)
+            rc = L.flex_plan_create_rows(C.byref(self._h), C.byref(v), int(rows[0]), int(rows[1]),
+                                         None if cm is None else cm.ctypes.data, k, device, order)
+        elif vo_mp is not None:
+            vm = np.ascontiguousarray(vo_mp, dtype=np.int32)
+            rc = L.flex_plan_create_mapped(C.byref(self._h), C.byref(v), vm.ctypes.data, k, device, order)
+        else:
+            rc = L.flex_plan_create(C.byref(self._h), C.byref(v), k, device, order)
+        _check(rc, "flex_plan_create")
+        self.k = k
+        self._keep = None  # the plan copies what it needs
+
+    def info(self) -> dict:
+        i = _PlanInfo()
+        _check(lib().flex_plan_get_info(self._h, C.byref(i)), "flex_plan_get_info")
+        return {f: getattr(i, f) for f, _ in _PlanInfo._fields_}
+
+    def spmm(self, dB_ptr: int, dC_ptr: int, stream: int = 0):
+        _check(lib().flex_spmm(self._h, dB_ptr, dC_ptr, stream), "flex_spmm")
+
+    def __call__(self, B, out=None):
+        """torch convenience: B is a cuda float32 [n,k] tensor; returns C [m,k]."""
+        import torch
+        i = self.info()
+        assert B.is_cuda and B.dtype == torch.float32 and B.is_contiguous() and tuple(B.shape) == (i["n"], i["k"])
+        if out is None:
+            out = torch.empty((i["m"], i["k"]), dtype=torch.float32, device=B.device)
+        self.spmm(B.data_ptr(), out.data_ptr(), torch.cuda.current_stream(B.device).cuda_stream)
+        return out
+
+    def destroy(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().flex_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def gather_rows(dst_ptr: int, src_ptr: int, idx_ptr: int, n: int, k: int, stream: int = 0):
+    _check(lib().flex_gather_rows(dst_ptr, src_ptr, idx_ptr, n, k, stream), "flex_gather_rows")

@@ -1,0 +1,55 @@
+// internal.h -- shared between the host planner and the HIP kernels of libflex_spmm.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/flex_spmm.h"
+
+namespace flex {
+
+// What the SpMM kernels read.  Passed by value as a kernel argument (the reference
+// copies a ~270-byte Mat_POD into __constant__ memory instead: mat.cuh:18-65, mat.cu:32-41).
+struct PlanView {
+    const uint2 *rec;        // [nnz] {x = B-row byte offset (off32) or column id, y = value bits}, task order
+    const uint32_t *t_beg;   // [n_tasks+1] first record of each task
+    const uint32_t *t_dst;   // [n_tasks]   C row written by the task; MSB set -> partial slot id
+    const uint32_t *w_task;  // [n_waves+1] first task of each wave
+    float *partial;          // [n_partials][k] partial sums of split rows
+    uint32_t n_waves;
+    int32_t k;
+};
+
+// One split row: C[row,:] = sum of partial[first .. first+count) in that order.
+struct SplitRow {
+    uint32_t row, first, count;
+};
+
+constexpr uint32_t kPartialFlag = 0x80000000u;
+constexpr int kWavesPerBlock = 4;  // 256-thread workgroups
+constexpr int kXcds = 8;           // MI355X: 8 XCDs, each with a private 4 MiB L2
+
+// per-thread record of the last HIP failure (flex_last_hip_error)
+void note_hip_error(hipError_t e);
+
+#define FLEX_HIP_TRY(expr)                          \
+    do {                                            \
+        hipError_t e_ = (expr);                     \
+        if (e_ != hipSuccess) {                     \
+            ::flex::note_hip_error(e_);             \
+            return FLEX_ERR_HIP;                    \
+        }                                           \
+    } while (0)
+
+// kernel launchers (spmm_kernels.hip)
+int launch_spmm(const PlanView &v, int lanes_per_nz, bool off32, bool vec4, const float *dB, float *dC,
+                hipStream_t s);
+int launch_fixup(const float *partial, const SplitRow *rows, uint32_t n_rows, int k, float *dC,
+                 hipStream_t s);
+int launch_gather_rows(float *dst, const float *src, const int32_t *idx, int64_t n, int k, hipStream_t s);
+
+// host-side helpers shared by the ABI files
+int order_rcm_host(int64_t n, const uint32_t *rowPtr, const uint32_t *col, std::vector<uint32_t> &rank);
+int validate_csr(const flex_csr *A);
+
+}  // namespace flex

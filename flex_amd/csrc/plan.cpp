@@ -1,0 +1,338 @@
+// plan.cpp -- host planner + the plan/launch half of the C ABI (include/flex_spmm.h).
+//
+// Replaces Mat::Mat / csr2_DiagTiling / alpha_transfer / launch_prep /
+// alpha_freeMatGPU (mat.cu:7-41, 268-293, 680-942; mat.cuh:184-193).  The
+// reference re-cuts A into diagonal "pillars" with per-SM queues and marks most
+// rows for atomicAdd; here the plan is a *schedule*: rows (optionally in RCM
+// order) are packed into per-wave runs of about equal nonzero count, rows longer
+// than two wave budgets are cut into chunks that write k-wide partial sums, and
+// column ids are pre-multiplied into B-row byte offsets.  Columns always refer to
+// the ORIGINAL B, rows always write the ORIGINAL C row, so no permuteX pass and
+// no shadow copy of B exist (flex.cu:276-289, mat.cu:287-290).
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <numeric>
+
+#include "internal.h"
+
+namespace flex {
+
+static thread_local hipError_t g_last_hip = hipSuccess;
+void note_hip_error(hipError_t e) { g_last_hip = e; }
+
+int validate_csr(const flex_csr *A) {
+    if (!A || A->m < 0 || A->n < 0 || A->nnz < 0) return FLEX_ERR_INVALID;
+    if (!A->rowPtr) return FLEX_ERR_INVALID;
+    if (A->nnz > 0 && (!A->col || !A->vals)) return FLEX_ERR_INVALID;
+    if (A->nnz >= (int64_t(1) << 32)) return FLEX_ERR_UNSUPPORTED;
+    if (A->rowPtr[0] != 0 || A->rowPtr[A->m] != static_cast<uint32_t>(A->nnz)) return FLEX_ERR_INVALID;
+    for (int32_t r = 0; r < A->m; ++r)
+        if (A->rowPtr[r] > A->rowPtr[r + 1]) return FLEX_ERR_INVALID;
+    const uint32_t n = static_cast<uint32_t>(A->n);
+    for (int64_t e = 0; e < A->nnz; ++e)
+        if (A->col[e] >= n) return FLEX_ERR_INVALID;
+    return FLEX_OK;
+}
+
+static long env_long(const char *name, long dflt) {
+    const char *s = std::getenv(name);
+    if (!s || !*s) return dflt;
+    char *e = nullptr;
+    long v = std::strtol(s, &e, 10);
+    return (e && *e == 0 && v > 0) ? v : dflt;
+}
+
+}  // namespace flex
+
+using namespace flex;
+
+struct flex_plan {
+    int32_t m = 0, n = 0, k = 0, device = 0;
+    int64_t nnz = 0;
+    int lanes_per_nz = 0;
+    bool off32 = false;
+    unsigned order = 0;
+    uint2 *d_rec = nullptr;
+    uint32_t *d_t_beg = nullptr, *d_t_dst = nullptr, *d_w_task = nullptr;
+    float *d_partial = nullptr;
+    SplitRow *d_split = nullptr;
+    uint32_t n_tasks = 0, n_waves = 0, n_split = 0, n_partials = 0;
+    int64_t device_bytes = 0;
+    double plan_ms = 0;
+};
+
+namespace {
+
+template <typename T>
+int upload(T **dptr, const std::vector<T> &h, int64_t *bytes) {
+    *dptr = nullptr;
+    const size_t nb = (h.empty() ? 1 : h.size()) * sizeof(T);
+    FLEX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(dptr), nb));
+    if (!h.empty()) FLEX_HIP_TRY(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *bytes += static_cast<int64_t>(nb);
+    return FLEX_OK;
+}
+
+void free_plan_device(flex_plan *p) {
+    (void)hipFree(p->d_rec);
+    (void)hipFree(p->d_t_beg);
+    (void)hipFree(p->d_t_dst);
+    (void)hipFree(p->d_w_task);
+    (void)hipFree(p->d_partial);
+    (void)hipFree(p->d_split);
+}
+
+// Rows [r0,r1) of A.  col_map: B row read by column c (NULL = c).  dst_map: C row
+// written by row r (NULL = r - r0, i.e. slice-local).
+int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const int32_t *col_map,
+               const int32_t *dst_map, unsigned flags) {
+    const int32_t m = r1 - r0;
+    const int k = p->k;
+    const unsigned order = flags & FLEX_ORDER_MASK;
+    if (order != FLEX_ORDER_NATURAL && order != FLEX_ORDER_RCM) return FLEX_ERR_INVALID;
+    // RCM needs the whole square (graph) matrix
+    if (order == FLEX_ORDER_RCM && (A->m != A->n || r0 != 0 || r1 != A->m)) return FLEX_ERR_INVALID;
+    p->order = order;
+
+    // 4*G >= min(k,256): G lanes x float4 cover one k-tile
+    int G = 8;
+    while (4 * G < k && G < 64) G <<= 1;
+    p->lanes_per_nz = G;
+    p->off32 = static_cast<uint64_t>(A->n) * static_cast<uint64_t>(k) * 4u <= (uint64_t(1) << 32);
+
+    // schedule: sched[i] = row of A processed i-th
+    std::vector<uint32_t> sched(m);
+    if (order == FLEX_ORDER_RCM) {
+        std::vector<uint32_t> rank;
+        int rc = order_rcm_host(m, A->rowPtr, A->col, rank);
+        if (rc) return rc;
+        for (int32_t r = 0; r < m; ++r) sched[rank[r]] = static_cast<uint32_t>(r);
+    } else {
+        std::iota(sched.begin(), sched.end(), static_cast<uint32_t>(r0));
+    }
+
+    // wave budget in nonzeros; rows longer than 2 budgets are cut into chunks
+    const uint32_t wave_nnz = static_cast<uint32_t>(env_long("FLEX_WAVE_NNZ", 256));
+    const uint32_t row_cost = static_cast<uint32_t>(env_long("FLEX_ROW_COST", 16));
+    const uint32_t long_row = 2 * wave_nnz;
+
+    std::vector<uint32_t> t_beg, t_dst, w_task;
+    std::vector<SplitRow> split;
+    std::vector<uint2> rec;
+    try {
+        t_beg.reserve(static_cast<size_t>(m) + 1);
+        t_dst.reserve(m);
+        rec.resize(static_cast<size_t>(A->rowPtr[r1] - A->rowPtr[r0]));
+    } catch (const std::bad_alloc &) {
+        return FLEX_ERR_NOMEM;
+    }
+    uint32_t n_partials = 0;
+    uint32_t zpos = 0;
+    uint32_t wave_cost = 0;
+    const uint32_t row_bytes32 = static_cast<uint32_t>(k) * 4u;
+    auto emit_records = [&](uint32_t e0, uint32_t e1) {
+        for (uint32_t e = e0; e < e1; ++e) {
+            uint32_t c = A->col[e];
+            if (col_map) c = static_cast<uint32_t>(col_map[c]);
+            uint32_t bits;
+            std::memcpy(&bits, &A->vals[e], 4);
+            rec[zpos++] = make_uint2(p->off32 ? c * row_bytes32 : c, bits);
+        }
+    };
+    constexpr uint32_t kMaxTasksPerWave = 63;  // kernel hands descriptors out by lane (spmm_v4_kernel)
+    auto open_wave_if_needed = [&]() {
+        if (w_task.empty() || wave_cost >= wave_nnz || t_dst.size() - w_task.back() >= kMaxTasksPerWave) {
+            w_task.push_back(static_cast<uint32_t>(t_dst.size()));
+            wave_cost = 0;
+        }
+    };
+    try {
+        for (int32_t i = 0; i < m; ++i) {
+            const uint32_t r = sched[i];
+            const uint32_t e0 = A->rowPtr[r], e1 = A->rowPtr[r + 1];
+            const uint32_t len = e1 - e0;
+            const uint32_t dst = dst_map ? static_cast<uint32_t>(dst_map[r]) : r - static_cast<uint32_t>(r0);
+            if (len > long_row) {
+                const uint32_t nchunk = (len + wave_nnz - 1) / wave_nnz;
+                const uint32_t per = (len + nchunk - 1) / nchunk;
+                split.push_back({dst, n_partials, 0});
+                for (uint32_t c0 = e0; c0 < e1; c0 += per) {
+                    const uint32_t c1 = std::min(e1, c0 + per);
+                    w_task.push_back(static_cast<uint32_t>(t_dst.size()));  // a chunk is a wave of its own
+                    t_beg.push_back(zpos);
+                    t_dst.push_back(kPartialFlag | n_partials++);
+                    emit_records(c0, c1);
+                    split.back().count++;
+                }
+                wave_cost = wave_nnz;  // force a fresh wave for the next row
+            } else {
+                open_wave_if_needed();
+                t_beg.push_back(zpos);
+                t_dst.push_back(dst);
+                emit_records(e0, e1);
+                wave_cost += len + row_cost;
+            }
+        }
+        t_beg.push_back(zpos);
+        w_task.push_back(static_cast<uint32_t>(t_dst.size()));
+    } catch (const std::bad_alloc &) {
+        return FLEX_ERR_NOMEM;
+    }
+    if (m == 0) w_task.assign(1, 0u);
+
+    p->n_tasks = static_cast<uint32_t>(t_dst.size());
+    p->n_waves = static_cast<uint32_t>(w_task.size() - 1);
+    p->n_split = static_cast<uint32_t>(split.size());
+    p->n_partials = n_partials;
+
+    int rc;
+    if ((rc = upload(&p->d_rec, rec, &p->device_bytes))) return rc;
+    if ((rc = upload(&p->d_t_beg, t_beg, &p->device_bytes))) return rc;
+    if ((rc = upload(&p->d_t_dst, t_dst, &p->device_bytes))) return rc;
+    if ((rc = upload(&p->d_w_task, w_task, &p->device_bytes))) return rc;
+    if ((rc = upload(&p->d_split, split, &p->device_bytes))) return rc;
+    const size_t pbytes = std::max<size_t>(1, static_cast<size_t>(n_partials) * k) * sizeof(float);
+    FLEX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_partial), pbytes));
+    p->device_bytes += static_cast<int64_t>(pbytes);
+    return FLEX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+static int create_common(flex_plan **out, const flex_csr *hostA, int64_t row_begin, int64_t row_end,
+                         const int32_t *col_map, const int32_t *dst_map, int k, int device, unsigned flags) {
+    if (!out) return FLEX_ERR_INVALID;
+    *out = nullptr;
+    if (k <= 0 || device < 0) return FLEX_ERR_INVALID;
+    const unsigned order = flags & FLEX_ORDER_MASK;
+    if (order != FLEX_ORDER_NATURAL && order != FLEX_ORDER_RCM) return FLEX_ERR_INVALID;
+    int rc = validate_csr(hostA);
+    if (rc) return rc;
+    if (hostA->m >= INT32_MAX) return FLEX_ERR_UNSUPPORTED;
+    if (row_begin < 0 || row_end < row_begin || row_end > hostA->m) return FLEX_ERR_INVALID;
+    if (col_map)
+        for (int32_t c = 0; c < hostA->n; ++c)
+            if (col_map[c] < 0 || col_map[c] >= hostA->n) return FLEX_ERR_INVALID;
+    if (dst_map)
+        for (int64_t r = row_begin; r < row_end; ++r)
+            if (dst_map[r] < 0 || dst_map[r] >= hostA->m) return FLEX_ERR_INVALID;
+    const auto t0 = std::chrono::steady_clock::now();
+    int prev = -1;
+    FLEX_HIP_TRY(hipGetDevice(&prev));
+    FLEX_HIP_TRY(hipSetDevice(device));
+    flex_plan *p = new (std::nothrow) flex_plan();
+    if (!p) return FLEX_ERR_NOMEM;
+    p->m = static_cast<int32_t>(row_end - row_begin);
+    p->n = hostA->n;
+    p->k = k;
+    p->nnz = static_cast<int64_t>(hostA->rowPtr[row_end]) - hostA->rowPtr[row_begin];
+    p->device = device;
+    rc = build_plan(p, hostA, static_cast<int32_t>(row_begin), static_cast<int32_t>(row_end), col_map, dst_map, flags);
+    if (rc == FLEX_OK && hipDeviceSynchronize() != hipSuccess) rc = FLEX_ERR_HIP;
+    (void)hipSetDevice(prev);
+    if (rc) {
+        free_plan_device(p);
+        delete p;
+        return rc;
+    }
+    p->plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *out = p;
+    return FLEX_OK;
+}
+
+int flex_plan_create(flex_plan **out, const flex_csr *hostA, int k, int device, unsigned flags) {
+    if (!hostA) return FLEX_ERR_INVALID;
+    // dst_map == NULL means slice-local rows, which for the full range is the identity
+    return create_common(out, hostA, 0, hostA->m, nullptr, nullptr, k, device, flags);
+}
+
+int flex_plan_create_mapped(flex_plan **out, const flex_csr *hostA, const int32_t *vo_mp, int k, int device,
+                            unsigned flags) {
+    if (!hostA) return FLEX_ERR_INVALID;
+    if (vo_mp && hostA->m != hostA->n) return FLEX_ERR_INVALID;
+    return create_common(out, hostA, 0, hostA->m, vo_mp, vo_mp, k, device, flags);
+}
+
+int flex_plan_create_rows(flex_plan **out, const flex_csr *hostA, int64_t row_begin, int64_t row_end,
+                          const int32_t *col_map, int k, int device, unsigned flags) {
+    if ((flags & FLEX_ORDER_MASK) != FLEX_ORDER_NATURAL) return FLEX_ERR_INVALID;
+    return create_common(out, hostA, row_begin, row_end, col_map, nullptr, k, device, flags);
+}
+
+int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream) {
+    if (!p) return FLEX_ERR_INVALID;
+    if (p->m == 0) return FLEX_OK;
+    if (!dC || (!dB && p->nnz > 0)) return FLEX_ERR_INVALID;
+    int cur = -1;
+    FLEX_HIP_TRY(hipGetDevice(&cur));
+    if (cur != p->device) FLEX_HIP_TRY(hipSetDevice(p->device));
+    PlanView v{p->d_rec, p->d_t_beg, p->d_t_dst, p->d_w_task, p->d_partial, p->n_waves, p->k};
+    const bool vec4 = (p->k % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(dB) | reinterpret_cast<uintptr_t>(dC)) % 16 == 0);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int rc = launch_spmm(v, p->lanes_per_nz, p->off32, vec4, dB, dC, s);
+    if (rc == FLEX_OK) rc = launch_fixup(p->d_partial, p->d_split, p->n_split, p->k, dC, s);
+    if (cur != p->device) (void)hipSetDevice(cur);
+    return rc;
+}
+
+int flex_plan_destroy(flex_plan *p) {
+    if (!p) return FLEX_OK;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    (void)hipSetDevice(p->device);
+    free_plan_device(p);
+    if (cur >= 0) (void)hipSetDevice(cur);
+    delete p;
+    return FLEX_OK;
+}
+
+int flex_plan_get_info(const flex_plan *p, flex_plan_info *o) {
+    if (!p || !o) return FLEX_ERR_INVALID;
+    o->m = p->m;
+    o->n = p->n;
+    o->k = p->k;
+    o->device = p->device;
+    o->nnz = p->nnz;
+    o->n_tasks = p->n_tasks;
+    o->n_waves = p->n_waves;
+    o->n_split_rows = p->n_split;
+    o->n_partials = p->n_partials;
+    o->device_bytes = p->device_bytes;
+    o->lanes_per_nz = p->lanes_per_nz;
+    o->order = static_cast<int32_t>(p->order);
+    o->plan_ms = p->plan_ms;
+    return FLEX_OK;
+}
+
+int flex_gather_rows(float *dst, const float *src, const int32_t *idx, int64_t n, int k, flex_stream_t stream) {
+    if (n < 0 || k <= 0) return FLEX_ERR_INVALID;
+    if (n == 0) return FLEX_OK;
+    if (!dst || !src || !idx) return FLEX_ERR_INVALID;
+    return launch_gather_rows(dst, src, idx, n, k, reinterpret_cast<hipStream_t>(stream));
+}
+
+const char *flex_strerror(int status) {
+    switch (status) {
+        case FLEX_OK: return "ok";
+        case FLEX_ERR_INVALID: return "invalid argument";
+        case FLEX_ERR_NOMEM: return "host allocation failed";
+        case FLEX_ERR_HIP: return "HIP runtime call failed (see flex_last_hip_error_string)";
+        case FLEX_ERR_UNSUPPORTED: return "shape not supported";
+        case FLEX_ERR_IO: return "file could not be read";
+        case FLEX_ERR_FORMAT: return "input does not parse as a 3-line CSR CSV";
+        case FLEX_ERR_DUPLICATE: return "duplicate (row,col) entry";
+        default: return "unknown flex status";
+    }
+}
+
+int flex_last_hip_error(void) { return static_cast<int>(g_last_hip); }
+const char *flex_last_hip_error_string(void) { return hipGetErrorString(g_last_hip); }
+int flex_abi_version(void) { return FLEX_ABI_VERSION; }
+
+}  // extern "C"

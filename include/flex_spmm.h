@@ -1,0 +1,178 @@
+/*
+ * flex_spmm.h -- C ABI of the MI355X-native SpMM engine (libflex_spmm.so).
+ *
+ * This is the drop-in boundary for the one hot path of guohaoqiang/Flex:
+ *     C[m x k] = A[m x n, CSR, fp32] * B[n x k, row-major fp32]
+ * The reference has no FFI layer; its seam is "host-side Mat/DataLoader objects
+ * -> kernel launch" (flex.cu:4979-4988, 5057-5059, 5690-5693).  Each entry point
+ * below names the reference code it replaces (paths relative to the reference
+ * tree).  Plain pointers and sizes only; nothing here throws, every function
+ * returns 0 (FLEX_OK) or a negative flex_status.  See INTEGRATION.md for the
+ * reference-side binding.
+ *
+ * There is deliberately NO CPU SpMM in this library: a missing GPU or a missing
+ * kernel is an error (FLEX_ERR_HIP / FLEX_ERR_UNSUPPORTED), never a fallback.
+ * The reference's CPU loop (aspt/sspmm_128.cu:1415-1422) lives in oracle/ as
+ * test infrastructure.
+ */
+#ifndef FLEX_SPMM_H
+#define FLEX_SPMM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLEX_ABI_VERSION 1
+
+typedef enum flex_status {
+    FLEX_OK = 0,
+    FLEX_ERR_INVALID = -1,     /* bad argument (null, negative size, k<=0, unsorted rowPtr, col>=n) */
+    FLEX_ERR_NOMEM = -2,       /* host allocation failed */
+    FLEX_ERR_HIP = -3,         /* a HIP runtime call failed (≙ CUDA_CHECK, common.h:53-60); see flex_last_hip_error */
+    FLEX_ERR_UNSUPPORTED = -4, /* shape outside what the kernels cover (nnz >= 2^32, m >= 2^31) */
+    FLEX_ERR_IO = -5,          /* file could not be opened / read */
+    FLEX_ERR_FORMAT = -6,      /* CSV does not parse (≙ stoi/stof throwing, assert(col.size()==vals.size()), DataLoader.cu:57) */
+    FLEX_ERR_DUPLICATE = -7    /* duplicate (row,col) (≙ assert(e_inv[dst].count(r)==0), DataLoader.cu:97) */
+} flex_status;
+
+/* Host CSR view: the three vectors of DataLoader (DataLoader.cuh:32-34) + sizes (:70).
+ * Indices are 32-bit unsigned exactly as in the reference. Not owned. */
+typedef struct flex_csr {
+    int32_t m, n;
+    int64_t nnz;
+    const uint32_t *rowPtr; /* m+1 */
+    const uint32_t *col;    /* nnz, any order within a row, must be < n */
+    const float *vals;      /* nnz */
+} flex_csr;
+
+/* HIP stream handle; identical to hipStream_t (pass torch's cuda_stream integer cast to a pointer). */
+typedef struct ihipStream_t *flex_stream_t;
+
+typedef struct flex_plan flex_plan;
+
+/* flags for flex_plan_create: bits 0-3 = row schedule */
+#define FLEX_ORDER_NATURAL 0u /* rows processed in the order given ("OVO") */
+#define FLEX_ORDER_RCM 1u     /* rows scheduled in the reference's RCM order (order_rcm.cu:15-33);
+                                 columns keep ORIGINAL ids, so B needs no permuteX pass and C
+                                 comes out in original row order */
+#define FLEX_ORDER_MASK 0xFu
+
+/* ≙ Mat::Mat + csr2_DiagTiling + alpha_transfer (mat.cu:7-31, 680-942, 268-293):
+ * builds the row-panel plan for `hostA` and uploads it to `device`.  The reference's
+ * pillar tiler is replaced by an nnz-balanced wave/row-panel planner. */
+int flex_plan_create(flex_plan **out, const flex_csr *hostA, int k, int device, unsigned flags);
+
+/* Same, for a CSR that a reordered loader already permuted (DataLoaderRcm &c.,
+ * DataLoader.cu:723-857): row r' of hostA is original row vo_mp[r'] and column c' is
+ * original column vo_mp[c'].  The plan folds both maps in at build time, so flex_spmm
+ * still takes B and returns C in ORIGINAL order (the reference needs permuteX +
+ * segVoMap for that: flex.cu:276-289, mat.cu:816-824). vo_mp==NULL means identity. */
+int flex_plan_create_mapped(flex_plan **out, const flex_csr *hostA, const int32_t *vo_mp, int k,
+                            int device, unsigned flags);
+
+/* Plan for the row slice [row_begin,row_end) of hostA only (a shard of a row-sharded
+ * multi-GPU run; the reference is single-GPU, flex.cu:4137).  flex_spmm then writes
+ * (row_end-row_begin) x k into dC, slice row 0 first; dB is still the full B.
+ * col_map (or NULL): column c of hostA reads B row col_map[c] -- pass the vo_mp of a
+ * reordered CSR to keep using the un-permuted B.  Rows are scheduled in the order given
+ * (flags must be FLEX_ORDER_NATURAL: reorder first, then shard). */
+int flex_plan_create_rows(flex_plan **out, const flex_csr *hostA, int64_t row_begin, int64_t row_end,
+                          const int32_t *col_map, int k, int device, unsigned flags);
+
+/* ≙ launch_prep + cudaMemset(C) + kernel<<<>>> (mat.cu:32-41, flex.cu:5057-5059).
+ * dB: n x k row-major device fp32; dC: m x k row-major device fp32, fully overwritten
+ * (alpha=1, beta=0 as in cuSpmm, flex.cu:5728-5729).  Asynchronous on `stream`;
+ * no allocation, no host sync (safe to capture in a hipGraph).  dB/dC must be
+ * 16-byte aligned when k % 4 == 0. */
+int flex_spmm(flex_plan *plan, const float *dB, float *dC, flex_stream_t stream);
+
+/* ≙ alpha_freeMatGPU (mat.cuh:184-193). */
+int flex_plan_destroy(flex_plan *plan);
+
+typedef struct flex_plan_info {
+    int32_t m, n, k, device;
+    int64_t nnz;
+    int64_t n_tasks;      /* wave tasks (rows + chunks of split rows) */
+    int64_t n_waves;      /* waves launched by the main kernel */
+    int64_t n_split_rows; /* rows long enough to be split over several waves */
+    int64_t n_partials;   /* k-wide partial sums held in the workspace */
+    int64_t device_bytes; /* HBM held by the plan */
+    int32_t lanes_per_nz; /* G: lanes that cooperate on one nonzero (k/4 rounded up to a power of two) */
+    int32_t order;        /* FLEX_ORDER_* actually applied */
+    double plan_ms;       /* host time spent planning + uploading */
+} flex_plan_info;
+int flex_plan_get_info(const flex_plan *plan, flex_plan_info *out);
+
+/* ≙ flexspmm_v9_permuteX (flex.cu:276-289): dst[r,:] = src[idx[r],:], n rows of k floats.
+ * Not needed by flex_spmm (plans fold the permutation in); provided for callers that
+ * keep the reference's B' ("shadow_b") layout. All pointers are device pointers. */
+int flex_gather_rows(float *dst, const float *src, const int32_t *idx, int64_t n, int k,
+                     flex_stream_t stream);
+
+/* ---- host-side ingest / reordering (C++ in the reference: DataLoader.cu) ---- */
+
+/* Owned host CSR + the statistics DataLoader computes (DataLoader.cu:26-29, 86-115). */
+typedef struct flex_host_csr {
+    int32_t m, n;
+    int64_t nnz;
+    uint32_t *rowPtr;
+    uint32_t *col;
+    float *vals;
+    int64_t uni_nb;
+    int64_t n_edges_one_way, n_edges_asymmetric;
+    int32_t n_nodes_z_out, n_nodes_z_in, n_nodes_z_deg;
+    int32_t is_directed;
+    int32_t c;
+} flex_host_csr;
+
+/* ≙ DataLoader::DataLoader (DataLoader.cu:9-124): 3-line CSV -> CSR (+ amazon.csv rule:
+ * no value line, vals = 2*rand()/RAND_MAX-1). */
+int flex_csv_load(const char *path, flex_host_csr *out);
+void flex_host_csr_free(flex_host_csr *a);
+
+/* ≙ cpuX fill in DataLoader::cuda_alloc_cpy (DataLoader.cu:198-209), glibc rand() stream. */
+int flex_fill_dense_rand(float *hostB, int64_t n, int k);
+
+/* ≙ order_rcm(h) (order_rcm.cu:15-33): rank[old] = new. */
+int flex_order_rcm(const flex_csr *A, uint32_t *rank);
+
+/* ≙ DataLoaderRcm body (DataLoader.cu:741-779): vo_mp[new]=old + permuted CSR, columns
+ * ascending per row. Outputs caller-allocated with the sizes of A. */
+int flex_perm_csr(const flex_csr *A, const uint32_t *rank, int32_t *vo_mp, uint32_t *rowPtr2,
+                  uint32_t *col2, float *vals2);
+
+/* ---- multi-GPU row sharding (new; the reference is single-GPU, flex.cu:4137) ---- */
+
+/* Contiguous row ranges of about equal cost, cost(row) = nnz(row)*(4k+8) + 4k bytes
+ * (gathered B bytes + records + the C row).  Writes nparts+1 row boundaries,
+ * row_bounds[0]=0 .. row_bounds[nparts]=m.  Each rank then builds its own plan on
+ * rows [row_bounds[r], row_bounds[r+1]) with flex_plan_create_rows. */
+int flex_shard_rows(const flex_csr *A, int k, int nparts, int64_t *row_bounds);
+
+/* ---- synthetic graphs with the README's shapes (README.md:13-20); data files are absent ---- */
+typedef struct flex_synth_params {
+    int64_t n;           /* vertices */
+    int64_t nnz;         /* exact nnz incl. one self-loop per row; nnz-n must be even (symmetric) */
+    double alpha;        /* power-law exponent of expected degrees (e.g. 2.1) */
+    int64_t community;   /* mean planted-community size (0 = none) */
+    double p_in;         /* fraction of edges kept inside a community */
+    double p_near;       /* fraction of edges that go to one of the 2*near_window neighbouring communities */
+    int32_t near_window; /* communities on either side counted as "near" */
+    int32_t shuffle;     /* 1: random vertex relabel so the natural order is not banded */
+    int32_t gcn_norm;    /* 1: vals = 1/sqrt(d_i d_j) (pubmed-like); 0: U(-1,1) */
+    uint64_t seed;
+} flex_synth_params;
+int flex_synth_graph(const flex_synth_params *p, flex_host_csr *out);
+
+const char *flex_strerror(int status);
+/* hipError_t of the last failed HIP call on this thread (0 if none) and its text. */
+int flex_last_hip_error(void);
+const char *flex_last_hip_error_string(void);
+int flex_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLEX_SPMM_H */

@@ -1,0 +1,151 @@
+"""CPU checks of the C-ABI library: it loads, exports every declared symbol, host entry points work."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import flex_amd
+import oracle
+from conftest import GOLDEN, ROOT
+from flex_amd import binding
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "flex_spmm.h")).read()
+    declared = set(re.findall(r"\b(flex_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(binding.SYMBOLS), declared ^ set(binding.SYMBOLS)
+    L = ctypes.CDLL(flex_amd.lib_path())
+    for s in declared:
+        assert hasattr(L, s), s
+    assert flex_amd.lib().flex_abi_version() == 1
+
+
+def test_no_cpu_spmm_symbol_in_product():
+    # the product must not carry a CPU SpMM (a fallback would void parity claims)
+    out = os.popen(f"nm -D --defined-only {flex_amd.lib_path()}").read()
+    assert "oracle" not in out and "spmm_host" not in out
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "flex_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "flex_oracle.h" not in txt, f
+
+
+@pytest.mark.parametrize("name", ["pubmed.csv", "a_mat.csv"])
+def test_ingest_equals_oracle(name):
+    a = flex_amd.csv_load(os.path.join(GOLDEN, name))
+    o = oracle.csv_load(os.path.join(GOLDEN, name))
+    assert np.array_equal(a.rowPtr, o.rowPtr) and np.array_equal(a.col, o.col)
+    assert np.array_equal(a.vals, o.vals)
+    for f in ("uni_nb", "n_edges_one_way", "n_edges_asymmetric", "n_nodes_z_out", "n_nodes_z_in",
+              "n_nodes_z_deg", "is_directed", "c"):
+        assert getattr(a, f) == getattr(o, f), f
+
+
+def test_ingest_errors(tmp_path):
+    with pytest.raises(flex_amd.FlexError, match="could not be read"):
+        flex_amd.csv_load(str(tmp_path / "nope.csv"))
+    bad = tmp_path / "bad.csv"
+    bad.write_text("0,2\n0,1\n1.0\n")
+    with pytest.raises(flex_amd.FlexError, match="does not parse"):
+        flex_amd.csv_load(str(bad))
+    dup = tmp_path / "dup.csv"
+    dup.write_text("0,2,2\n1,1\n1.0,2.0\n")
+    with pytest.raises(flex_amd.FlexError, match="duplicate"):
+        flex_amd.csv_load(str(dup))
+    junk = tmp_path / "junk.csv"
+    junk.write_text("0,x\n0\n1.0\n")
+    with pytest.raises(flex_amd.FlexError):
+        flex_amd.csv_load(str(junk))
+
+
+def test_amazon_rule_and_rand_fill(tmp_path):
+    f = tmp_path / "amazon.csv"
+    f.write_text("0,1,2\n1,0\n")
+    ctypes.CDLL(None).srand(1)
+    a = flex_amd.csv_load(str(f))
+    B = flex_amd.fill_dense_rand(2, 1)
+    assert np.allclose(a.vals, [0.680375, -0.211234], atol=5e-7) and a.c == 107
+    assert np.allclose(B.ravel(), [0.566198, 0.59688], atol=5e-7)
+    ctypes.CDLL(None).srand(1)
+    assert np.array_equal(flex_amd.fill_dense_rand(50, 8), oracle.gen_B(50, 8))
+
+
+def test_rcm_equals_oracle_on_pubmed_and_synthetic(golden):
+    a = flex_amd.csv_load(os.path.join(GOLDEN, "pubmed.csv"))
+    rank = flex_amd.order_rcm(a)
+    assert np.array_equal(rank.astype(np.uint64), oracle.order_rcm(a.rowPtr, a.col))
+    vo, a2 = flex_amd.perm_csr(a, rank)
+    assert np.array_equal(vo, golden["pubmed_rcm_vo_mp"])
+    vo2, rp2, c2, v2 = oracle.perm_csr(a.rowPtr, a.col, a.vals, rank.astype(np.uint64))
+    assert np.array_equal(a2.rowPtr, rp2) and np.array_equal(a2.col, c2) and np.array_equal(a2.vals, v2)
+    # directed toy graph (a_mat): out-adjacency BFS, several components
+    t = flex_amd.csv_load(os.path.join(GOLDEN, "a_mat.csv"))
+    assert np.array_equal(flex_amd.order_rcm(t).astype(np.uint64), oracle.order_rcm(t.rowPtr, t.col))
+    g = flex_amd.synth_graph(n=3000, nnz=3000 + 2 * 9000, community=50, p_in=0.5, p_near=0.2, seed=3)
+    assert np.array_equal(flex_amd.order_rcm(g).astype(np.uint64), oracle.order_rcm(g.rowPtr, g.col))
+
+
+def test_synth_graph_shape_and_determinism():
+    g = flex_amd.synth_graph(n=5000, nnz=5000 + 2 * 30000, community=100, p_in=0.6, p_near=0.2, seed=9)
+    h = flex_amd.synth_graph(n=5000, nnz=5000 + 2 * 30000, community=100, p_in=0.6, p_near=0.2, seed=9)
+    assert (g.m, g.nnz) == (5000, 65000)
+    assert np.array_equal(g.rowPtr, h.rowPtr) and np.array_equal(g.col, h.col) and np.array_equal(g.vals, h.vals)
+    rows = np.repeat(np.arange(g.m), np.diff(g.rowPtr.astype(np.int64)))
+    # symmetric, self loop on every row, strictly sorted columns, GCN-normalised values
+    key = rows.astype(np.int64) * g.n + g.col
+    keyT = g.col.astype(np.int64) * g.n + rows
+    assert np.array_equal(np.sort(key), np.sort(keyT))
+    assert np.all(np.diff(key) > 0)
+    assert np.count_nonzero(rows == g.col) == g.m
+    deg = np.diff(g.rowPtr.astype(np.int64))
+    assert np.allclose(g.vals, 1 / np.sqrt(deg[rows] * deg[g.col]), rtol=1e-6)
+    with pytest.raises(flex_amd.FlexError):
+        flex_amd.synth_graph(n=10, nnz=13)  # nnz - n odd
+
+
+def test_flickr_preset_has_readme_shape():
+    g = flex_amd.synth_graph("flickr")
+    assert (g.m, g.nnz) == (89250, 989006)  # README.md:16
+
+
+def test_shard_rows_balances_cost():
+    g = flex_amd.synth_graph(n=20000, nnz=20000 + 2 * 200000, community=200, p_in=0.6, p_near=0.2, seed=5)
+    for parts in (1, 2, 3, 8):
+        b = flex_amd.shard_rows(g, 128, parts)
+        assert b[0] == 0 and b[-1] == g.m and np.all(np.diff(b) >= 0)
+        cost = np.diff(g.rowPtr.astype(np.int64)) * (4 * 128 + 8) + 4 * 128
+        per = np.array([cost[b[i]:b[i + 1]].sum() for i in range(parts)], dtype=np.float64)
+        assert per.max() <= per.mean() * 1.02 + cost.max()
+
+
+def test_plan_argument_validation():
+    L = flex_amd.lib()
+    h = ctypes.c_void_p()
+    good = flex_amd.HostCsr([0, 1], [0], [1.0])
+    v = good.view()
+    assert L.flex_plan_create(ctypes.byref(h), None, 32, 0, 0) == -1
+    assert L.flex_plan_create(None, ctypes.byref(v), 32, 0, 0) == -1
+    assert L.flex_plan_create(ctypes.byref(h), ctypes.byref(v), 0, 0, 0) == -1
+    assert L.flex_plan_create(ctypes.byref(h), ctypes.byref(v), 32, -1, 0) == -1
+    bad = flex_amd.HostCsr([0, 1], [5], [1.0])  # column out of range
+    vb = bad.view()
+    assert L.flex_plan_create(ctypes.byref(h), ctypes.byref(vb), 32, 0, 0) == -1
+    assert L.flex_plan_create(ctypes.byref(h), ctypes.byref(v), 32, 0, 7) == -1  # unknown order
+    assert L.flex_spmm(None, None, None, None) == -1
+    assert L.flex_plan_destroy(None) == 0
+    assert L.flex_strerror(-3).decode().startswith("HIP runtime call failed")
+
+
+def test_no_gpu_fails_loudly_never_falls_back():
+    torch = pytest.importorskip("torch")
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the loud-failure path needs a box without one")
+    good = flex_amd.HostCsr([0, 1], [0], [1.0])
+    with pytest.raises(flex_amd.FlexError, match="HIP runtime call failed"):
+        flex_amd.Plan(good, 32)

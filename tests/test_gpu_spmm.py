@@ -1,0 +1,229 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+
+Tolerance (north_star: "within a stated fp32 tolerance") is the reference's own resCheck
+(flex.cu:4154-4213): per element err = |g|<1 ? |g-r| : |1-r/g| must not exceed
+4 * FLT_EPSILON * nnz(row); zero elements may exceed it.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import flex_amd
+import oracle
+from conftest import GOLDEN
+from flex_amd import FLEX_ORDER_NATURAL, FLEX_ORDER_RCM, Plan
+from util import assert_matches_oracle, random_B, random_csr
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def run_plan(plan, B):
+    C = plan(dev(B))
+    torch.cuda.synchronize()
+    return C.cpu().numpy()
+
+
+def test_library_is_the_hip_one():
+    assert torch.cuda.is_available()
+    assert os.path.exists(flex_amd.lib_path())
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+
+
+def test_a_mat_golden(golden):
+    a = flex_amd.csv_load(os.path.join(GOLDEN, "a_mat.csv"))
+    B = golden["a_mat_k8_B"]
+    C = run_plan(Plan(a, 8), B)
+    cnt, max_err, _, _ = oracle.rescheck(golden["a_mat_k8_C"], C, a.rowPtr)
+    assert cnt == 0 and max_err < 1e-5
+
+
+@pytest.mark.parametrize("k", [32, 128])
+@pytest.mark.parametrize("order", [FLEX_ORDER_NATURAL, FLEX_ORDER_RCM])
+def test_pubmed_vs_oracle_and_golden(golden, k, order):
+    a = flex_amd.csv_load(os.path.join(GOLDEN, "pubmed.csv"))
+    B = oracle.gen_B(a.n, k)  # the reference's rand() B (DataLoader.cu:198-209)
+    C = run_plan(Plan(a, k, order=order), B)
+    gold, max_err = assert_matches_oracle(a, B, C)
+    # committed golden vectors: sampled elements and the fp64 checksum of the fp32 C
+    idx = golden[f"pubmed_k{k}_idx"]
+    deg = np.diff(a.rowPtr.astype(np.int64))[idx // k]
+    g = golden[f"pubmed_k{k}_C_at_idx"]
+    assert np.all(np.abs(C.ravel()[idx] - g) <= 4 * np.finfo(np.float32).eps * deg * np.maximum(1, np.abs(g)))
+    assert abs(C.astype(np.float64).sum() - float(golden[f"pubmed_k{k}_C_sum"])) < 1e-2
+    if k == 32:  # the reference's own figure
+        assert abs(C.astype(np.float64).sum() - 666.878358) < 1e-2
+
+
+@pytest.mark.parametrize("k", [1, 3, 4, 8, 12, 16, 20, 32, 64, 96, 100, 128, 256, 260, 384, 512])
+def test_k_sweep_ragged(k):
+    a = random_csr(700, 900, 9, seed=k, long_rows={5: 800, 699: 600, 123: 513}, empty_frac=0.15)
+    B = random_B(a.n, k, seed=1000 + k)
+    p = Plan(a, k)
+    info = p.info()
+    assert info["n_split_rows"] >= 2 and info["n_partials"] >= 4
+    assert_matches_oracle(a, B, run_plan(p, B))
+
+
+def test_empty_and_degenerate():
+    # all rows empty -> C must be overwritten with zeros (beta = 0)
+    a = flex_amd.HostCsr(np.zeros(6, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.float32), n=7)
+    p = Plan(a, 32)
+    C = torch.full((5, 32), 7.0, device="cuda")
+    p.spmm(dev(random_B(7, 32, 0)).data_ptr(), C.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.count_nonzero(C).item() == 0
+    # zero rows
+    z = flex_amd.HostCsr(np.zeros(1, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.float32), n=3)
+    Plan(z, 16).spmm(0, 0, 0)
+    # single dense row, single column matrix
+    one = flex_amd.HostCsr(np.array([0, 1], np.uint32), np.array([0], np.uint32), np.array([2.0], np.float32), n=1)
+    assert np.array_equal(run_plan(Plan(one, 4), np.array([[1, 2, 3, 4]], np.float32)), [[2, 4, 6, 8]])
+
+
+def test_unsorted_columns_and_duplicates_are_summed():
+    # mtx2csr.cc:171-195 emits unsorted columns; duplicates simply add up in CSR SpMM
+    a = flex_amd.HostCsr(np.array([0, 4, 5], np.uint32), np.array([3, 0, 3, 1, 2], np.uint32),
+                         np.array([1, 2, 3, 4, 5], np.float32), n=4)
+    B = random_B(4, 32, 3)
+    assert_matches_oracle(a, B, run_plan(Plan(a, 32), B))
+
+
+def test_inf_nan_only_reach_rows_that_reference_them():
+    a = random_csr(300, 300, 7, seed=5, empty_frac=0.0)
+    B = random_B(300, 128, 6)
+    B[17, :] = np.inf
+    B[18, 5] = np.nan
+    C = run_plan(Plan(a, 128), B)
+    gold = oracle.spmm(a.rowPtr, a.col, a.vals, B)
+    assert np.array_equal(np.isfinite(C), np.isfinite(gold))
+    fin = np.isfinite(gold)
+    assert np.allclose(C[fin], gold[fin], rtol=1e-5, atol=1e-5)
+
+
+def test_rcm_schedule_and_mapped_plan_agree_with_natural():
+    a = flex_amd.synth_graph(n=6000, nnz=6000 + 2 * 40000, community=64, p_in=0.6, p_near=0.2, seed=11)
+    k = 64
+    B = random_B(a.n, k, 12)
+    gold, _ = assert_matches_oracle(a, B, run_plan(Plan(a, k), B))
+    # (1) RCM as a schedule inside the plan: same B, C in original order
+    assert_matches_oracle(a, B, run_plan(Plan(a, k, order=FLEX_ORDER_RCM), B))
+    # (2) the reference's flow: DataLoaderRcm permutes the CSR, plan folds vo_mp back in
+    rank = flex_amd.order_rcm(a)
+    vo, a2 = flex_amd.perm_csr(a, rank)
+    C2 = run_plan(Plan(a2, k, vo_mp=vo), B)
+    cnt, _, _, _ = oracle.rescheck(gold, C2, a.rowPtr)
+    assert cnt == 0
+    # (3) the reference's literal flow with permuteX: B' = B[vo_mp], C' in RCM order
+    Bd = dev(B)
+    Bp = torch.empty_like(Bd)
+    flex_amd.gather_rows(Bp.data_ptr(), Bd.data_ptr(), dev(vo).data_ptr(), a.n, k,
+                         torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(Bp.cpu().numpy(), B[vo])
+    C3 = run_plan(Plan(a2, k), B[vo])
+    unperm = np.empty_like(C3)
+    unperm[vo] = C3
+    assert oracle.rescheck(gold, unperm, a.rowPtr)[0] == 0
+
+
+def test_row_shards_concatenate_to_full():
+    a = random_csr(5000, 5000, 20, seed=21, long_rows={7: 3000})
+    k = 128
+    B = random_B(a.n, k, 22)
+    full = run_plan(Plan(a, k), B)
+    bounds = flex_amd.shard_rows(a, k, 4)
+    assert bounds[0] == 0 and bounds[-1] == a.m and np.all(np.diff(bounds) > 0)
+    parts = [run_plan(Plan(a, k, rows=(bounds[i], bounds[i + 1])), B) for i in range(4)]
+    assert np.array_equal(np.concatenate(parts), full)  # same schedule per row -> bit-identical
+    assert_matches_oracle(a, B, full)
+
+
+def test_unaligned_buffers_take_the_generic_kernel():
+    a = random_csr(400, 500, 11, seed=31)
+    k = 32
+    B = random_B(a.n, k, 32)
+    buf = torch.zeros(a.n * k + 1, device="cuda")
+    buf[1:] = dev(B).ravel()
+    out = torch.zeros(a.m * k + 1, device="cuda")
+    Plan(a, k).spmm(buf[1:].data_ptr(), out[1:].data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert_matches_oracle(a, B, out[1:].reshape(a.m, k).cpu().numpy())
+
+
+def test_deterministic_and_overwrites_output():
+    a = random_csr(3000, 3000, 30, seed=41, long_rows={0: 2500, 1500: 2000})
+    k = 128
+    B = dev(random_B(a.n, k, 42))
+    p = Plan(a, k)
+    C1 = p(B)
+    C2 = torch.full_like(C1, float("nan"))
+    p(B, out=C2)
+    torch.cuda.synchronize()
+    assert torch.equal(C1, C2)
+
+
+def test_hip_graph_capture():
+    # flex_spmm allocates nothing and never syncs, so it can be captured (cdna guide G9)
+    a = random_csr(2000, 2000, 15, seed=51, long_rows={3: 1200})
+    k = 128
+    Bn = random_B(a.n, k, 52)
+    B = dev(Bn)
+    C = torch.zeros((a.m, k), device="cuda")
+    p = Plan(a, k)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        p(B, out=C)  # warm-up outside capture
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        p(B, out=C)
+    C.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert_matches_oracle(a, Bn, C.cpu().numpy())
+
+
+def test_flickr_shape_full_size_vs_oracle():
+    # BASELINE config[1]: Flickr shape (89250^2, 989006 nnz), k=128 -- small enough for the oracle
+    a = flex_amd.synth_graph("flickr")
+    assert (a.m, a.nnz) == (89250, 989006)
+    B = random_B(a.n, 128, 61)
+    for order in (FLEX_ORDER_NATURAL, FLEX_ORDER_RCM):
+        assert_matches_oracle(a, B, run_plan(Plan(a, 128, order=order), B), nthreads=8)
+
+
+def test_large_properties_checksum_and_linearity():
+    # size-independent checks at a size the scalar oracle would be slow on
+    a = flex_amd.synth_graph(n=200000, nnz=200000 + 2 * 4000000, community=1024, p_in=0.6, p_near=0.2,
+                             alpha=2.1, seed=71)
+    k = 128
+    p = Plan(a, k, order=FLEX_ORDER_RCM)
+    # B = ones -> every column of C is the row sum of A (checksum of checksums)
+    ones = torch.ones((a.n, k), device="cuda")
+    C = p(ones).cpu().numpy()
+    rows = np.repeat(np.arange(a.m), np.diff(a.rowPtr.astype(np.int64)))
+    rowsum = np.bincount(rows, weights=a.vals.astype(np.float64), minlength=a.m)
+    deg = np.diff(a.rowPtr.astype(np.int64))
+    tol = 4 * np.finfo(np.float32).eps * np.maximum(deg, 1) * np.maximum(1.0, np.abs(rowsum))
+    assert np.all(np.abs(C - rowsum[:, None]) <= tol[:, None])
+    # linearity: A(B1 + B2) == A B1 + A B2 within the same tolerance scale
+    B1, B2 = dev(random_B(a.n, k, 72)), dev(random_B(a.n, k, 73))
+    lhs = p(B1 + B2).cpu().numpy().astype(np.float64)
+    rhs = p(B1).cpu().numpy().astype(np.float64) + p(B2).cpu().numpy()
+    assert np.all(np.abs(lhs - rhs) <= 8 * np.finfo(np.float32).eps * np.maximum(deg, 1)[:, None] * 2.0)
+    # sampled rows against the oracle arithmetic
+    samp = np.random.default_rng(7).choice(a.m, 2000, replace=False)
+    B1h = B1.cpu().numpy()
+    C1 = p(B1).cpu().numpy()
+    for r in samp[:200]:
+        cols = a.col[a.rowPtr[r]:a.rowPtr[r + 1]]
+        v = a.vals[a.rowPtr[r]:a.rowPtr[r + 1]]
+        ref = (v[:, None].astype(np.float64) * B1h[cols]).sum(axis=0)
+        assert np.all(np.abs(C1[r] - ref) <= 4 * np.finfo(np.float32).eps * len(cols) * np.maximum(1, np.abs(ref)))
