@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--k", type=int, default=128)
     ap.add_argument("--order", default="rcm", choices=["rcm", "natural"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--shuffle", type=int, default=1, help="0: keep the generator's planted order (locality upper bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="verify rank 0's shard against the oracle (small workloads)")
     return ap.parse_args()
@@ -69,7 +70,7 @@ def main():
         nnz0 -= 1
     t_gen = time.perf_counter()
     a = flex_amd.synth_graph(n=n0 * scale, nnz=nnz0 * scale, alpha=alpha, community=comm, p_in=p_in,
-                             p_near=p_near, near_window=win, gcn_norm=bool(gcn),
+                             p_near=p_near, near_window=win, gcn_norm=bool(gcn), shuffle=bool(args.shuffle),
                              seed=0xF1E0 + sorted(flex_amd.SYNTH_PRESETS).index(args.workload))
     t_gen = time.perf_counter() - t_gen
 

@@ -9,6 +9,7 @@ no compute path of its own and raises if the HIP library is missing.
 from .binding import (  # noqa: F401
     FLEX_ORDER_NATURAL,
     FLEX_ORDER_RCM,
+    FLEX_ORDER_CLUSTER,
     FlexError,
     HostCsr,
     Plan,
@@ -19,6 +20,7 @@ from .binding import (  # noqa: F401
     lib,
     lib_path,
     order_rcm,
+    order_cluster,
     perm_csr,
     shard_rows,
     synth_graph,

@@ -19,6 +19,7 @@ _SO = os.path.join(_HERE, "lib", "libflex_spmm.so")
 
 FLEX_ORDER_NATURAL = 0
 FLEX_ORDER_RCM = 1
+FLEX_ORDER_CLUSTER = 2
 
 
 class FlexError(RuntimeError):
@@ -59,7 +60,7 @@ class _SynthParams(C.Structure):  # flex_synth_params
 SYMBOLS = [
     "flex_plan_create", "flex_plan_create_mapped", "flex_plan_create_rows", "flex_spmm",
     "flex_plan_destroy", "flex_plan_get_info", "flex_gather_rows", "flex_csv_load",
-    "flex_host_csr_free", "flex_fill_dense_rand", "flex_order_rcm", "flex_perm_csr",
+    "flex_host_csr_free", "flex_fill_dense_rand", "flex_order_rcm", "flex_order_cluster", "flex_perm_csr",
     "flex_shard_rows", "flex_synth_graph", "flex_strerror", "flex_last_hip_error",
     "flex_last_hip_error_string", "flex_abi_version",
 ]
@@ -107,6 +108,7 @@ def lib():
         L.flex_host_csr_free.restype = None
         L.flex_fill_dense_rand.argtypes = [vp, i64, i32]
         L.flex_order_rcm.argtypes = [C.POINTER(_Csr), vp]
+        L.flex_order_cluster.argtypes = [C.POINTER(_Csr), vp]
         L.flex_perm_csr.argtypes = [C.POINTER(_Csr), vp, vp, vp, vp, vp]
         L.flex_shard_rows.argtypes = [C.POINTER(_Csr), i32, i32, vp]
         L.flex_synth_graph.argtypes = [C.POINTER(_SynthParams), C.POINTER(_HostCsr)]
@@ -175,6 +177,13 @@ def order_rcm(a: HostCsr) -> np.ndarray:
     rank = np.empty(max(a.m, 1), dtype=np.uint32)
     v = a.view()
     _check(lib().flex_order_rcm(C.byref(v), rank.ctypes.data), "flex_order_rcm")
+    return rank[: a.m]
+
+
+def order_cluster(a: HostCsr) -> np.ndarray:
+    rank = np.empty(max(a.m, 1), dtype=np.uint32)
+    v = a.view()
+    _check(lib().flex_order_cluster(C.byref(v), rank.ctypes.data), "flex_order_cluster")
     return rank[: a.m]
 
 

@@ -18,6 +18,9 @@ struct PlanView {
     float *partial;          // [n_partials][k] partial sums of split rows
     uint32_t n_waves;
     int32_t k;
+    uint32_t xcd_remap;      // 1: workgroup ids are remapped so each XCD walks a contiguous schedule slice
+    uint32_t variant;        // 0: flat-stream kernel (default); 1: per-row kernel (kept for A/B timing)
+    uint32_t lds_extra;      // bytes of unused dynamic LDS per workgroup (occupancy throttle)
 };
 
 // One split row: C[row,:] = sum of partial[first .. first+count) in that order.
@@ -50,6 +53,7 @@ int launch_gather_rows(float *dst, const float *src, const int32_t *idx, int64_t
 
 // host-side helpers shared by the ABI files
 int order_rcm_host(int64_t n, const uint32_t *rowPtr, const uint32_t *col, std::vector<uint32_t> &rank);
+int order_cluster_host(int64_t n, const uint32_t *rowPtr, const uint32_t *col, std::vector<uint32_t> &rank);
 int validate_csr(const flex_csr *A);
 
 }  // namespace flex

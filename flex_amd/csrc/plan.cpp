@@ -54,6 +54,9 @@ struct flex_plan {
     int64_t nnz = 0;
     int lanes_per_nz = 0;
     bool off32 = false;
+    bool xcd_remap = true;
+    unsigned variant = 0;
+    unsigned lds_extra = 0;
     unsigned order = 0;
     uint2 *d_rec = nullptr;
     uint32_t *d_t_beg = nullptr, *d_t_dst = nullptr, *d_w_task = nullptr;
@@ -92,9 +95,9 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     const int32_t m = r1 - r0;
     const int k = p->k;
     const unsigned order = flags & FLEX_ORDER_MASK;
-    if (order != FLEX_ORDER_NATURAL && order != FLEX_ORDER_RCM) return FLEX_ERR_INVALID;
-    // RCM needs the whole square (graph) matrix
-    if (order == FLEX_ORDER_RCM && (A->m != A->n || r0 != 0 || r1 != A->m)) return FLEX_ERR_INVALID;
+    if (order > FLEX_ORDER_CLUSTER) return FLEX_ERR_INVALID;
+    // graph orderings need the whole square matrix
+    if (order != FLEX_ORDER_NATURAL && (A->m != A->n || r0 != 0 || r1 != A->m)) return FLEX_ERR_INVALID;
     p->order = order;
 
     // 4*G >= min(k,256): G lanes x float4 cover one k-tile
@@ -105,9 +108,10 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
 
     // schedule: sched[i] = row of A processed i-th
     std::vector<uint32_t> sched(m);
-    if (order == FLEX_ORDER_RCM) {
+    if (order != FLEX_ORDER_NATURAL) {
         std::vector<uint32_t> rank;
-        int rc = order_rcm_host(m, A->rowPtr, A->col, rank);
+        int rc = order == FLEX_ORDER_RCM ? order_rcm_host(m, A->rowPtr, A->col, rank)
+                                         : order_cluster_host(m, A->rowPtr, A->col, rank);
         if (rc) return rc;
         for (int32_t r = 0; r < m; ++r) sched[rank[r]] = static_cast<uint32_t>(r);
     } else {
@@ -118,6 +122,10 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     const uint32_t wave_nnz = static_cast<uint32_t>(env_long("FLEX_WAVE_NNZ", 256));
     const uint32_t row_cost = static_cast<uint32_t>(env_long("FLEX_ROW_COST", 16));
     const uint32_t long_row = 2 * wave_nnz;
+    p->xcd_remap = env_long("FLEX_XCD_REMAP", 1) != 2;  // 2 = off (tuning experiments only)
+    p->variant = env_long("FLEX_KERNEL", 1) == 2 ? 1u : 0u;  // 2 = per-row kernel (A/B timing only)
+    p->lds_extra = static_cast<unsigned>(env_long("FLEX_LDS_EXTRA", 1)) & ~15u;  // default 0 (1 -> 0)
+    const uint32_t S = 64u / static_cast<uint32_t>(G);      // records per step: rows are padded to it
 
     std::vector<uint32_t> t_beg, t_dst, w_task;
     std::vector<SplitRow> split;
@@ -125,12 +133,11 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     try {
         t_beg.reserve(static_cast<size_t>(m) + 1);
         t_dst.reserve(m);
-        rec.resize(static_cast<size_t>(A->rowPtr[r1] - A->rowPtr[r0]));
+        rec.reserve(static_cast<size_t>(A->rowPtr[r1] - A->rowPtr[r0]) + static_cast<size_t>(m) * (S - 1) / 2 + 64);
     } catch (const std::bad_alloc &) {
         return FLEX_ERR_NOMEM;
     }
     uint32_t n_partials = 0;
-    uint32_t zpos = 0;
     uint32_t wave_cost = 0;
     const uint32_t row_bytes32 = static_cast<uint32_t>(k) * 4u;
     auto emit_records = [&](uint32_t e0, uint32_t e1) {
@@ -139,8 +146,10 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
             if (col_map) c = static_cast<uint32_t>(col_map[c]);
             uint32_t bits;
             std::memcpy(&bits, &A->vals[e], 4);
-            rec[zpos++] = make_uint2(p->off32 ? c * row_bytes32 : c, bits);
+            rec.push_back(make_uint2(p->off32 ? c * row_bytes32 : c, bits));
         }
+        // pad to a whole number of steps: value 0, B row = the last real one (always a valid address)
+        while (e1 > e0 && rec.size() % S != 0) rec.push_back(make_uint2(rec.back().x, 0u));
     };
     constexpr uint32_t kMaxTasksPerWave = 63;  // kernel hands descriptors out by lane (spmm_v4_kernel)
     auto open_wave_if_needed = [&]() {
@@ -157,12 +166,12 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
             const uint32_t dst = dst_map ? static_cast<uint32_t>(dst_map[r]) : r - static_cast<uint32_t>(r0);
             if (len > long_row) {
                 const uint32_t nchunk = (len + wave_nnz - 1) / wave_nnz;
-                const uint32_t per = (len + nchunk - 1) / nchunk;
+                const uint32_t per = ((len + nchunk - 1) / nchunk + S - 1) / S * S;  // whole steps
                 split.push_back({dst, n_partials, 0});
                 for (uint32_t c0 = e0; c0 < e1; c0 += per) {
                     const uint32_t c1 = std::min(e1, c0 + per);
                     w_task.push_back(static_cast<uint32_t>(t_dst.size()));  // a chunk is a wave of its own
-                    t_beg.push_back(zpos);
+                    t_beg.push_back(static_cast<uint32_t>(rec.size()));
                     t_dst.push_back(kPartialFlag | n_partials++);
                     emit_records(c0, c1);
                     split.back().count++;
@@ -170,18 +179,19 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
                 wave_cost = wave_nnz;  // force a fresh wave for the next row
             } else {
                 open_wave_if_needed();
-                t_beg.push_back(zpos);
+                t_beg.push_back(static_cast<uint32_t>(rec.size()));
                 t_dst.push_back(dst);
                 emit_records(e0, e1);
                 wave_cost += len + row_cost;
             }
         }
-        t_beg.push_back(zpos);
+        t_beg.push_back(static_cast<uint32_t>(rec.size()));
         w_task.push_back(static_cast<uint32_t>(t_dst.size()));
     } catch (const std::bad_alloc &) {
         return FLEX_ERR_NOMEM;
     }
     if (m == 0) w_task.assign(1, 0u);
+    if (rec.size() >= (size_t(1) << 32)) return FLEX_ERR_UNSUPPORTED;  // 32-bit record offsets
 
     p->n_tasks = static_cast<uint32_t>(t_dst.size());
     p->n_waves = static_cast<uint32_t>(w_task.size() - 1);
@@ -210,7 +220,7 @@ static int create_common(flex_plan **out, const flex_csr *hostA, int64_t row_beg
     *out = nullptr;
     if (k <= 0 || device < 0) return FLEX_ERR_INVALID;
     const unsigned order = flags & FLEX_ORDER_MASK;
-    if (order != FLEX_ORDER_NATURAL && order != FLEX_ORDER_RCM) return FLEX_ERR_INVALID;
+    if (order > FLEX_ORDER_CLUSTER) return FLEX_ERR_INVALID;
     int rc = validate_csr(hostA);
     if (rc) return rc;
     if (hostA->m >= INT32_MAX) return FLEX_ERR_UNSUPPORTED;
@@ -271,7 +281,7 @@ int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream) {
     int cur = -1;
     FLEX_HIP_TRY(hipGetDevice(&cur));
     if (cur != p->device) FLEX_HIP_TRY(hipSetDevice(p->device));
-    PlanView v{p->d_rec, p->d_t_beg, p->d_t_dst, p->d_w_task, p->d_partial, p->n_waves, p->k};
+    PlanView v{p->d_rec, p->d_t_beg, p->d_t_dst, p->d_w_task, p->d_partial, p->n_waves, p->k, p->xcd_remap ? 1u : 0u, p->variant, p->lds_extra};
     const bool vec4 = (p->k % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(dB) | reinterpret_cast<uintptr_t>(dC)) % 16 == 0);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

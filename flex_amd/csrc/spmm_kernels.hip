@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void spmm_v4_kernel(PlanView p, const float *_
     // XCD-aware remap: hardware deals consecutive workgroup ids round-robin over the 8
     // XCDs; give XCD x the contiguous schedule slice [x*cpx, (x+1)*cpx). gridDim.x % 8 == 0.
     const uint32_t cpx = gridDim.x / kXcds;
-    const uint32_t bid = (blockIdx.x % kXcds) * cpx + (blockIdx.x / kXcds);
+    const uint32_t bid = p.xcd_remap ? (blockIdx.x % kXcds) * cpx + (blockIdx.x / kXcds) : blockIdx.x;
     const uint32_t w = bid * kWavesPerBlock + wib;
     if (w >= p.n_waves) return;
 
@@ -172,6 +172,107 @@ __global__ __launch_bounds__(256) void spmm_v4_kernel(PlanView p, const float *_
     }
 }
 
+// ---------------------------------------------------------------------------
+// Flat-stream kernel (the default).  Rows of GNN graphs are short (median degree
+// < 10), so a per-row loop restarts its load -> gather -> reduce dependency chain
+// every few nonzeros and leaves a wave with 2-3 loads in flight.  Here a wave
+// treats ALL its records as one stream of steps (S records per step; the planner
+// pads every row to a multiple of S with zero-valued records): the records of a
+// window are fetched once, coalesced, into a wave-private LDS slice, then blocks
+// of U gathers are issued back to back regardless of row boundaries, and a
+// wave-uniform scalar check after each step flushes the accumulator when a row
+// ends.  No barriers: the LDS slice is private to the wave.
+// ---------------------------------------------------------------------------
+constexpr int kWindowRecs = 256;  // records staged per wave and window (2 KiB of LDS)
+
+template <int G, bool OFF32, int U>
+__global__ __launch_bounds__(256) void spmm_flat_kernel(PlanView p, const float *__restrict__ B,
+                                                        float *__restrict__ C) {
+    constexpr int S = 64 / G;
+    __shared__ uint2 lds_rec[kWavesPerBlock][kWindowRecs];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t cpx = gridDim.x / kXcds;
+    const uint32_t bid = p.xcd_remap ? (blockIdx.x % kXcds) * cpx + (blockIdx.x / kXcds) : blockIdx.x;
+    const uint32_t w = bid * kWavesPerBlock + wib;
+    if (w >= p.n_waves) return;
+
+    const int slot = lane / G;
+    const int sub = lane % G;
+    const int k = p.k;
+    const int c0 = blockIdx.y * (4 * G) + sub * 4;
+    const bool col_ok = c0 < k;
+    const uint32_t lane_off = (col_ok ? c0 : 0) * 4u;
+    const char *Bb = reinterpret_cast<const char *>(B);
+    const uint64_t row_bytes = static_cast<uint64_t>(k) * 4u;
+    const uint2 *__restrict__ rec = p.rec;
+    uint2 *my_lds = lds_rec[wib];
+
+    const uint32_t t0 = p.w_task[w], t1 = p.w_task[w + 1];
+    const uint32_t nt = t1 - t0;  // <= 63 (planner invariant)
+    const uint32_t my_beg = (static_cast<uint32_t>(lane) <= nt) ? p.t_beg[t0 + lane] : 0u;
+    const uint32_t my_dst = (static_cast<uint32_t>(lane) < nt) ? p.t_dst[t0 + lane] : 0u;
+    const uint32_t zb = __builtin_amdgcn_readlane(my_beg, 0);
+    const uint32_t ze = __builtin_amdgcn_readlane(my_beg, nt);
+
+    uint32_t ti = 0;                                          // current task
+    uint32_t row_end = __builtin_amdgcn_readlane(my_beg, 1);  // where it ends in the record stream
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+
+    // write out every task that ends at stream position `pos` (several when rows are empty)
+    auto drain = [&](uint32_t pos) {
+        while (ti < nt && row_end == pos) {
+            float4 r = acc;
+#pragma unroll
+            for (int off = G; off < 64; off <<= 1) {
+                r.x += __shfl_xor(r.x, off);
+                r.y += __shfl_xor(r.y, off);
+                r.z += __shfl_xor(r.z, off);
+                r.w += __shfl_xor(r.w, off);
+            }
+            const uint32_t dst = __builtin_amdgcn_readlane(my_dst, ti);
+            if (slot == 0 && col_ok) {
+                if (dst & kPartialFlag) {
+                    *reinterpret_cast<float4 *>(p.partial + static_cast<uint64_t>(dst & ~kPartialFlag) * k + c0) = r;
+                } else {
+                    const v4f val = {r.x, r.y, r.z, r.w};
+                    __builtin_nontemporal_store(val, reinterpret_cast<v4f *>(C + static_cast<uint64_t>(dst) * k + c0));
+                }
+            }
+            acc = {0.f, 0.f, 0.f, 0.f};
+            ++ti;
+            row_end = __builtin_amdgcn_readlane(my_beg, ti + 1 <= nt ? ti + 1 : nt);
+        }
+    };
+    drain(zb);  // leading empty rows
+
+    for (uint32_t wz = zb; wz < ze; wz += kWindowRecs) {
+        const uint32_t wn = min(static_cast<uint32_t>(kWindowRecs), ze - wz);
+        // stage this window's records: coalesced 512-B loads, one ds_write_b64 per lane and load
+#pragma unroll
+        for (int i = 0; i < kWindowRecs / 64; ++i) {
+            const uint32_t idx = i * 64 + lane;
+            if (idx < wn) my_lds[idx] = rec[wz + idx];
+        }
+        const uint32_t nsteps = wn / S;  // rows are padded to multiples of S
+        for (uint32_t j = 0; j < nsteps; j += U) {
+            uint2 r[U];
+            float4 b[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) r[u] = my_lds[min(j + u, nsteps - 1) * S + slot];
+#pragma unroll
+            for (int u = 0; u < U; ++u) b[u] = gather4<OFF32>(Bb, r[u].x, lane_off, row_bytes);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (j + u < nsteps) {  // wave-uniform
+                    fma4(acc, as_f32(r[u].y), b[u]);
+                    drain(wz + (j + u + 1) * S);
+                }
+            }
+        }
+    }
+}
+
 // Any k (k % 4 != 0 or unaligned B/C): one wave per task, lane owns columns
 // lane, lane+64, lane+128, lane+192 of the blockIdx.y-th 256-column tile.
 template <bool OFF32>
@@ -180,7 +281,7 @@ __global__ __launch_bounds__(256) void spmm_generic_kernel(PlanView p, const flo
     const int lane = threadIdx.x & 63;
     const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t cpx = gridDim.x / kXcds;
-    const uint32_t bid = (blockIdx.x % kXcds) * cpx + (blockIdx.x / kXcds);
+    const uint32_t bid = p.xcd_remap ? (blockIdx.x % kXcds) * cpx + (blockIdx.x / kXcds) : blockIdx.x;
     const uint32_t w = bid * kWavesPerBlock + wib;
     if (w >= p.n_waves) return;
     const int k = p.k;
@@ -251,7 +352,11 @@ int launch_v4(const PlanView &v, const float *dB, float *dC, hipStream_t s) {
     uint32_t nblk = (v.n_waves + kWavesPerBlock - 1) / kWavesPerBlock;
     nblk = (nblk + kXcds - 1) / kXcds * kXcds;
     const uint32_t ktiles = (v.k + 4 * G - 1) / (4 * G);
-    hipLaunchKernelGGL((spmm_v4_kernel<G, OFF32, U>), dim3(nblk, ktiles), dim3(256), 0, s, v, dB, dC);
+    // lds_extra: unused dynamic LDS that only lowers the number of resident workgroups per CU
+    if (v.variant == 1)
+        hipLaunchKernelGGL((spmm_v4_kernel<G, OFF32, (U > 4 ? 8 : 4)>), dim3(nblk, ktiles), dim3(256), v.lds_extra, s, v, dB, dC);
+    else
+        hipLaunchKernelGGL((spmm_flat_kernel<G, OFF32, U>), dim3(nblk, ktiles), dim3(256), v.lds_extra, s, v, dB, dC);
     FLEX_HIP_TRY(hipGetLastError());
     return FLEX_OK;
 }
@@ -280,7 +385,7 @@ int launch_spmm(const PlanView &v, int lanes_per_nz, bool off32, bool vec4, cons
     switch (lanes_per_nz) {
         case 8: return launch_v4_off<8, 4>(v, off32, dB, dC, s);
         case 16: return launch_v4_off<16, 4>(v, off32, dB, dC, s);
-        case 32: return launch_v4_off<32, 4>(v, off32, dB, dC, s);
+        case 32: return launch_v4_off<32, 8>(v, off32, dB, dC, s);
         case 64: return launch_v4_off<64, 8>(v, off32, dB, dC, s);
         default: return FLEX_ERR_UNSUPPORTED;
     }

@@ -57,6 +57,9 @@ typedef struct flex_plan flex_plan;
 #define FLEX_ORDER_RCM 1u     /* rows scheduled in the reference's RCM order (order_rcm.cu:15-33);
                                  columns keep ORIGINAL ids, so B needs no permuteX pass and C
                                  comes out in original row order */
+#define FLEX_ORDER_CLUSTER 2u /* rows scheduled community by community (agglomerative modularity
+                                 clustering, ≙ DataLoaderRabbit, DataLoader.cu:453-655); same
+                                 no-permutation contract as FLEX_ORDER_RCM */
 #define FLEX_ORDER_MASK 0xFu
 
 /* ≙ Mat::Mat + csr2_DiagTiling + alpha_transfer (mat.cu:7-31, 680-942, 268-293):
@@ -137,6 +140,10 @@ int flex_fill_dense_rand(float *hostB, int64_t n, int k);
 
 /* ≙ order_rcm(h) (order_rcm.cu:15-33): rank[old] = new. */
 int flex_order_rcm(const flex_csr *A, uint32_t *rank);
+
+/* ≙ the clustering half of DataLoaderRabbit (DataLoader.cu:453-655): rank[old] = new such
+ * that communities (and their sub-communities) are consecutive. */
+int flex_order_cluster(const flex_csr *A, uint32_t *rank);
 
 /* ≙ DataLoaderRcm body (DataLoader.cu:741-779): vo_mp[new]=old + permuted CSR, columns
  * ascending per row. Outputs caller-allocated with the sizes of A. */
