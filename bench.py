@@ -8,7 +8,7 @@ A "step" is one flex_spmm() over the whole (sharded) matrix with A's plan and B 
 in HBM.  N=1 workload: BASELINE.json configs[1], the Flickr shape (89250^2, 989006 nnz),
 k=128, fp32 -- a synthetic stand-in with exactly that n and nnz (the reference ships only
 pubmed.csv).  N>1: weak scaling -- the same generator at N x n vertices and N x nnz
-nonzeros, RCM-reordered, rows sharded over the ranks by flex_shard_rows, B broadcast once
+nonzeros, reordered (community schedule), rows sharded over the ranks by flex_shard_rows, B broadcast once
 over RCCL (torch.distributed "nccl") before the timed region; no collective on the data path.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and
@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="flickr", help="synthetic preset: flickr|reddit|amazon|yelp|ppi|pubmed")
     ap.add_argument("--k", type=int, default=128)
-    ap.add_argument("--order", default="rcm", choices=["rcm", "natural"])
+    ap.add_argument("--order", default="cluster", choices=["cluster", "rcm", "natural"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--shuffle", type=int, default=1, help="0: keep the generator's planted order (locality upper bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -76,14 +76,16 @@ def main():
 
     # ---- plan: RCM is a schedule (N=1) or an explicit permutation followed by row sharding (N>1)
     t_plan = time.perf_counter()
-    order = flex_amd.FLEX_ORDER_RCM if args.order == "rcm" else flex_amd.FLEX_ORDER_NATURAL
+    order = {"cluster": flex_amd.FLEX_ORDER_CLUSTER, "rcm": flex_amd.FLEX_ORDER_RCM,
+             "natural": flex_amd.FLEX_ORDER_NATURAL}[args.order]
     if world == 1:
         plan = flex_amd.Plan(a, k, device=local_rank, order=order)
         shard_nnz, shard_rows = a.nnz, a.m
         a_local, vo, r0, r1 = a, None, 0, a.m
     else:
-        if args.order == "rcm":
-            vo, a_local = flex_amd.perm_csr(a, flex_amd.order_rcm(a))
+        if args.order != "natural":
+            rank = flex_amd.order_rcm(a) if args.order == "rcm" else flex_amd.order_cluster(a)
+            vo, a_local = flex_amd.perm_csr(a, rank)
         else:
             vo, a_local = None, a
         bounds = flex_amd.shard_rows(a_local, k, world)
@@ -158,7 +160,7 @@ def main():
         ms_per_step = wall * 1e3 / args.steps
         flops = 2.0 * a.nnz * k  # all ranks together process every nonzero once per step
         gflops = flops / (wall / args.steps) / 1e9
-        # roofline of the dominant kernel (spmm_v4_kernel): algorithmic bytes of ONE launch on this
+        # roofline of the dominant kernel (spmm_flat_kernel): algorithmic bytes of ONE launch on this
         # rank = rowPtr + (col,val) + B read once + C written once  (flex.cu:4672)
         b_alg = 4.0 * (shard_rows + 1) + 8.0 * shard_nnz + 4.0 * a.n * k + 4.0 * shard_rows * k
         kern_ms = dev_ms / args.steps
@@ -172,13 +174,13 @@ def main():
                 "workload": f"{args.workload}-shape synthetic graph x{scale} (n={a.n}, nnz={a.nnz}), k={k}, fp32, "
                             f"{args.order} schedule" + (f", rows sharded over {world} GPUs, B broadcast once" if world > 1 else ""),
                 "n": a.n, "nnz": a.nnz, "k": k, "order": args.order, "parallelism": f"row-shard x{world}",
-                "plan": {"waves": info["n_waves"], "tasks": info["n_tasks"], "split_rows": info["n_split_rows"],
+                "plan": {"chunks": info["n_chunks"], "tasks": info["n_tasks"], "split_rows": info["n_split_rows"],
                          "lanes_per_nz": info["lanes_per_nz"], "plan_s": round(t_plan, 3), "gen_s": round(t_gen, 3)},
                 "b_bcast_ms": round(bcast_ms, 3),
             },
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(args, world),
-                         "kernel": "spmm_v4_kernel", "kernel_ms": round(kern_ms, 6),
+                         "kernel": "spmm_flat_kernel", "kernel_ms": round(kern_ms, 6),
                          "algorithmic_bytes_per_launch": int(b_alg)},
         }
         if ok is not None:

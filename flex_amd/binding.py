@@ -43,7 +43,7 @@ class _HostCsr(C.Structure):  # flex_host_csr
 
 class _PlanInfo(C.Structure):  # flex_plan_info
     _fields_ = [("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("device", C.c_int32),
-                ("nnz", C.c_int64), ("n_tasks", C.c_int64), ("n_waves", C.c_int64),
+                ("nnz", C.c_int64), ("n_tasks", C.c_int64), ("n_chunks", C.c_int64),
                 ("n_split_rows", C.c_int64), ("n_partials", C.c_int64),
                 ("device_bytes", C.c_int64), ("lanes_per_nz", C.c_int32), ("order", C.c_int32),
                 ("plan_ms", C.c_double)]

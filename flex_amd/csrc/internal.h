@@ -14,14 +14,15 @@ struct PlanView {
     const uint2 *rec;        // [nnz] {x = B-row byte offset (off32) or column id, y = value bits}, task order
     const uint32_t *t_beg;   // [n_tasks+1] first record of each task
     const uint32_t *t_dst;   // [n_tasks]   C row written by the task; MSB set -> partial slot id
-    const uint32_t *w_task;  // [n_waves+1] first task of each wave
+    const uint4 *chunk;      // [n_chunks] {first task, #tasks (<= 63), first record, end record}; one wave per chunk
     float *partial;          // [n_partials][k] partial sums of split rows
-    uint32_t n_waves;
+    uint32_t n_chunks;
     int32_t k;
-    uint32_t xcd_remap;      // 1: workgroup ids are remapped so each XCD walks a contiguous schedule slice
-    uint32_t variant;        // 0: flat-stream kernel (default); 1: per-row kernel (kept for A/B timing)
-    uint32_t lds_extra;      // bytes of unused dynamic LDS per workgroup (occupancy throttle)
+    uint32_t xcd_remap;      // 1: remap workgroup ids so each XCD walks one contiguous slice of the schedule
+    uint32_t lds_extra;      // bytes of unused dynamic LDS per workgroup (occupancy throttle, tuning only)
+    uint64_t *trace;         // diagnostic builds (-DFLEX_TRACE) only: 6 words per wave; nullptr otherwise
 };
+
 
 // One split row: C[row,:] = sum of partial[first .. first+count) in that order.
 struct SplitRow {

@@ -55,14 +55,15 @@ struct flex_plan {
     int lanes_per_nz = 0;
     bool off32 = false;
     bool xcd_remap = true;
-    unsigned variant = 0;
     unsigned lds_extra = 0;
+    uint64_t *trace = nullptr;
     unsigned order = 0;
     uint2 *d_rec = nullptr;
-    uint32_t *d_t_beg = nullptr, *d_t_dst = nullptr, *d_w_task = nullptr;
+    uint32_t *d_t_beg = nullptr, *d_t_dst = nullptr;
+    uint4 *d_chunk = nullptr;
     float *d_partial = nullptr;
     SplitRow *d_split = nullptr;
-    uint32_t n_tasks = 0, n_waves = 0, n_split = 0, n_partials = 0;
+    uint32_t n_tasks = 0, n_chunks = 0, n_split = 0, n_partials = 0;
     int64_t device_bytes = 0;
     double plan_ms = 0;
 };
@@ -83,7 +84,7 @@ void free_plan_device(flex_plan *p) {
     (void)hipFree(p->d_rec);
     (void)hipFree(p->d_t_beg);
     (void)hipFree(p->d_t_dst);
-    (void)hipFree(p->d_w_task);
+    (void)hipFree(p->d_chunk);
     (void)hipFree(p->d_partial);
     (void)hipFree(p->d_split);
 }
@@ -119,11 +120,15 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     }
 
     // wave budget in nonzeros; rows longer than 2 budgets are cut into chunks
-    const uint32_t wave_nnz = static_cast<uint32_t>(env_long("FLEX_WAVE_NNZ", 256));
+    // chunk budget: short chunks keep the dispatcher's load balancing fine-grained on low-degree
+    // graphs (flickr: best at ~96 records), long ones amortise the per-chunk descriptor chain on
+    // high-degree graphs (reddit: best at >= 256).  Measured on MI355X, DESIGN.md 3.3.
+    const double avg_deg = m > 0 ? static_cast<double>(A->rowPtr[r1] - A->rowPtr[r0]) / m : 0.0;
+    const long auto_budget = std::clamp<long>(static_cast<long>(8.0 * avg_deg), 96, 256);
+    const uint32_t wave_nnz = static_cast<uint32_t>(env_long("FLEX_WAVE_NNZ", auto_budget));
     const uint32_t row_cost = static_cast<uint32_t>(env_long("FLEX_ROW_COST", 16));
     const uint32_t long_row = 2 * wave_nnz;
     p->xcd_remap = env_long("FLEX_XCD_REMAP", 1) != 2;  // 2 = off (tuning experiments only)
-    p->variant = env_long("FLEX_KERNEL", 1) == 2 ? 1u : 0u;  // 2 = per-row kernel (A/B timing only)
     p->lds_extra = static_cast<unsigned>(env_long("FLEX_LDS_EXTRA", 1)) & ~15u;  // default 0 (1 -> 0)
     const uint32_t S = 64u / static_cast<uint32_t>(G);      // records per step: rows are padded to it
 
@@ -194,7 +199,7 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     if (rec.size() >= (size_t(1) << 32)) return FLEX_ERR_UNSUPPORTED;  // 32-bit record offsets
 
     p->n_tasks = static_cast<uint32_t>(t_dst.size());
-    p->n_waves = static_cast<uint32_t>(w_task.size() - 1);
+    p->n_chunks = static_cast<uint32_t>(w_task.size() - 1);
     p->n_split = static_cast<uint32_t>(split.size());
     p->n_partials = n_partials;
 
@@ -202,7 +207,10 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     if ((rc = upload(&p->d_rec, rec, &p->device_bytes))) return rc;
     if ((rc = upload(&p->d_t_beg, t_beg, &p->device_bytes))) return rc;
     if ((rc = upload(&p->d_t_dst, t_dst, &p->device_bytes))) return rc;
-    if ((rc = upload(&p->d_w_task, w_task, &p->device_bytes))) return rc;
+    std::vector<uint4> chunk(p->n_chunks);
+    for (uint32_t c = 0; c < p->n_chunks; ++c)
+        chunk[c] = make_uint4(w_task[c], w_task[c + 1] - w_task[c], t_beg[w_task[c]], t_beg[w_task[c + 1]]);
+    if ((rc = upload(&p->d_chunk, chunk, &p->device_bytes))) return rc;
     if ((rc = upload(&p->d_split, split, &p->device_bytes))) return rc;
     const size_t pbytes = std::max<size_t>(1, static_cast<size_t>(n_partials) * k) * sizeof(float);
     FLEX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_partial), pbytes));
@@ -281,7 +289,8 @@ int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream) {
     int cur = -1;
     FLEX_HIP_TRY(hipGetDevice(&cur));
     if (cur != p->device) FLEX_HIP_TRY(hipSetDevice(p->device));
-    PlanView v{p->d_rec, p->d_t_beg, p->d_t_dst, p->d_w_task, p->d_partial, p->n_waves, p->k, p->xcd_remap ? 1u : 0u, p->variant, p->lds_extra};
+    PlanView v{p->d_rec, p->d_t_beg, p->d_t_dst, p->d_chunk, p->d_partial, p->n_chunks, p->k,
+               p->xcd_remap ? 1u : 0u, p->lds_extra, p->trace};
     const bool vec4 = (p->k % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(dB) | reinterpret_cast<uintptr_t>(dC)) % 16 == 0);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -310,7 +319,7 @@ int flex_plan_get_info(const flex_plan *p, flex_plan_info *o) {
     o->device = p->device;
     o->nnz = p->nnz;
     o->n_tasks = p->n_tasks;
-    o->n_waves = p->n_waves;
+    o->n_chunks = p->n_chunks;
     o->n_split_rows = p->n_split;
     o->n_partials = p->n_partials;
     o->device_bytes = p->device_bytes;
@@ -326,6 +335,15 @@ int flex_gather_rows(float *dst, const float *src, const int32_t *idx, int64_t n
     if (!dst || !src || !idx) return FLEX_ERR_INVALID;
     return launch_gather_rows(dst, src, idx, n, k, reinterpret_cast<hipStream_t>(stream));
 }
+
+#ifdef FLEX_TRACE
+// diagnostic build only (libflex_spmm_trace.so, tools/trace.py); not part of the ABI
+int flex_debug_set_trace(flex_plan *p, uint64_t *dev_log) {
+    if (!p) return FLEX_ERR_INVALID;
+    p->trace = dev_log;
+    return FLEX_OK;
+}
+#endif
 
 const char *flex_strerror(int status) {
     switch (status) {

@@ -4,26 +4,31 @@
 // alpha_w_atomic_spmm_v36, flex.cu:4008-4124; closest in structure: spmm_test2,
 // flex.cu:190-273).  None of that code is reused.  Design:
 //
-//  * A *task* is one C row (or one chunk of a long row); a *wave* owns a short
-//    contiguous run of tasks chosen by the host planner so that every wave has
-//    about the same number of nonzeros.  No inter-wave communication, no
-//    atomics, no barriers, no LDS: the kernel is a pure gather stream.
-//  * k/4 lanes (G) cooperate on one nonzero, each lane owning 4 consecutive
+//  * A *task* is one C row (or one piece of a long row); a *chunk* is a short
+//    contiguous run of tasks cut by the host planner so that every chunk holds
+//    about the same number of (col,val) records.
+//  * One wave per chunk; workgroup ids are remapped so that each XCD (private
+//    4 MiB L2) walks its own contiguous eighth of the schedule with one cursor:
+//    rows that are neighbours in the schedule share B rows through that L2, and
+//    the hardware dispatcher (a new workgroup whenever one retires) does the
+//    load balancing that the reference builds by hand with per-SM buckets plus
+//    a balance bucket (flex.cu:2447-2518, 4008-4124).
+//  * k/4 lanes (G) cooperate on one record, each lane owning 4 consecutive
 //    columns of C, so one wave-instruction gathers 64/G different B rows with
 //    16-byte loads (k=128: two 512-B rows = 1 KiB per global_load_dwordx4;
-//    k=32: eight 128-B rows).  The 64/G slots of a wave walk the SAME row with
-//    stride 64/G and are combined by a log2(64/G)-step xor-shuffle at row end.
-//  * U independent gathers are issued per lane before the first FMA so that
-//    every wave keeps U KiB in flight; the tail of a row is one branch-free
-//    block of exactly the leftover step count, so short rows (GNN graphs:
-//    median degree < 10) still issue all their gathers back to back.
-//  * Workgroup ids are remapped so that each XCD (private 4 MiB L2) walks its
-//    own contiguous eighth of the schedule: rows that are neighbours in the
-//    (RCM) schedule share B rows through that XCD's L2.
-//  * C is written once with non-temporal 16-byte stores; rows split over
-//    several waves go to a k-wide partial slot instead and are summed, in a
-//    fixed order, by a second tiny kernel (deterministic; the reference uses
-//    atomicAdd for its split rows, mat.cu:816-824).
+//    k=32: eight 128-B rows).  The S = 64/G slots of a wave walk the SAME row
+//    and are combined by a log2(S)-step xor-shuffle at row end.
+//  * Rows of GNN graphs are short (median degree < 10), so the wave treats ALL
+//    records of a chunk as one stream of steps (S records per step; the planner
+//    pads every row to a multiple of S with zero-valued records): the records are
+//    fetched once, coalesced, into a wave-private LDS slice, then blocks of U
+//    gathers are issued back to back regardless of row boundaries, and a
+//    wave-uniform scalar check after each step flushes the accumulator when a row
+//    ends.  No barriers: LDS slices are private to a wave.
+//  * C is written once with non-temporal 16-byte stores; rows cut into several
+//    pieces go to k-wide partial slots instead and are summed, in a fixed order,
+//    by a second tiny kernel (deterministic; the reference uses atomicAdd for its
+//    split rows, mat.cu:816-824).
 #include "internal.h"
 
 namespace flex {
@@ -49,171 +54,63 @@ __device__ __forceinline__ void fma4(float4 &acc, float v, const float4 &b) {
     acc.w = fmaf(v, b.w, acc.w);
 }
 
-// N steps of S nonzeros starting at z.  With PRED, steps whose record index falls at or
-// past `ze` are neutralised without branches: the index is clamped to the row's last
-// record (so every address stays valid and the N gathers still issue back to back) and
-// both the value and the gathered B entries are zeroed (0*inf must not leak in).
-template <int N, int S, bool OFF32, bool PRED>
-__device__ __forceinline__ void steps(float4 &acc, const uint2 *__restrict__ rec, const char *__restrict__ Bb,
-                                      uint32_t z, uint32_t ze, int slot, uint32_t lane_off,
-                                      uint64_t row_bytes) {
-    uint2 r[N];
-    float4 b[N];
-    bool ok[N];
-#pragma unroll
-    for (int u = 0; u < N; ++u) {
-        uint32_t zi = z + u * S + slot;
-        ok[u] = PRED ? (zi < ze) : true;
-        if (PRED) zi = min(zi, ze - 1);
-        r[u] = rec[zi];
-    }
-#pragma unroll
-    for (int u = 0; u < N; ++u) b[u] = gather4<OFF32>(Bb, r[u].x, lane_off, row_bytes);
-#pragma unroll
-    for (int u = 0; u < N; ++u) {
-        float v = as_f32(r[u].y);
-        if (PRED) {
-            v = ok[u] ? v : 0.f;
-            b[u].x = ok[u] ? b[u].x : 0.f;
-            b[u].y = ok[u] ? b[u].y : 0.f;
-            b[u].z = ok[u] ? b[u].z : 0.f;
-            b[u].w = ok[u] ? b[u].w : 0.f;
-        }
-        fma4(acc, v, b[u]);
-    }
-}
-
-// the 1..U steps left after the unrolled loop, as ONE block of exactly that many
-// gathers (wave-uniform switch), only the last step predicated per lane
-template <int U, int S, bool OFF32>
-__device__ __forceinline__ void tail_steps(uint32_t rem, float4 &acc, const uint2 *__restrict__ rec,
-                                           const char *__restrict__ Bb, uint32_t z, uint32_t ze, int slot,
-                                           uint32_t lane_off, uint64_t row_bytes) {
-#define FLEX_TAIL_CASE(N)                                                                  \
-    case N:                                                                                \
-        if constexpr (N <= U) steps<N, S, OFF32, true>(acc, rec, Bb, z, ze, slot, lane_off, row_bytes); \
-        break;
-    switch (rem) {
-        FLEX_TAIL_CASE(1)
-        FLEX_TAIL_CASE(2)
-        FLEX_TAIL_CASE(3)
-        FLEX_TAIL_CASE(4)
-        FLEX_TAIL_CASE(5)
-        FLEX_TAIL_CASE(6)
-        FLEX_TAIL_CASE(7)
-        FLEX_TAIL_CASE(8)
-        default: break;
-    }
-#undef FLEX_TAIL_CASE
-}
-
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// G lanes per nonzero, 4 columns per lane; covers k <= 4*G per blockIdx.y tile.
-template <int G, bool OFF32, int U>
-__global__ __launch_bounds__(256) void spmm_v4_kernel(PlanView p, const float *__restrict__ B,
-                                                      float *__restrict__ C) {
-    constexpr int S = 64 / G;
-    static_assert(U >= 2 && U <= 8, "tail_steps covers 1..7 leftover steps");
-    const int lane = threadIdx.x & 63;
-    const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // XCD-aware remap: hardware deals consecutive workgroup ids round-robin over the 8
-    // XCDs; give XCD x the contiguous schedule slice [x*cpx, (x+1)*cpx). gridDim.x % 8 == 0.
-    const uint32_t cpx = gridDim.x / kXcds;
-    const uint32_t bid = p.xcd_remap ? (blockIdx.x % kXcds) * cpx + (blockIdx.x / kXcds) : blockIdx.x;
-    const uint32_t w = bid * kWavesPerBlock + wib;
-    if (w >= p.n_waves) return;
-
-    const int slot = lane / G;
-    const int sub = lane % G;
-    const int k = p.k;
-    const int c0 = blockIdx.y * (4 * G) + sub * 4;  // first of this lane's 4 columns
-    const bool col_ok = c0 < k;                      // k % 4 == 0 on this path
-    const uint32_t lane_off = (col_ok ? c0 : 0) * 4u;
-    const char *Bb = reinterpret_cast<const char *>(B);
-    const uint64_t row_bytes = static_cast<uint64_t>(k) * 4u;
-    const uint2 *__restrict__ rec = p.rec;
-
-    // A wave owns at most 63 tasks (planner invariant): fetch all its descriptors with one
-    // coalesced load per array and hand them out with v_readlane, so the per-row critical
-    // path has no dependent descriptor load in it.
-    const uint32_t t0 = p.w_task[w], t1 = p.w_task[w + 1];
-    const uint32_t nt = t1 - t0;
-    const uint32_t my_beg = (static_cast<uint32_t>(lane) <= nt) ? p.t_beg[t0 + lane] : 0u;
-    const uint32_t my_dst = (static_cast<uint32_t>(lane) < nt) ? p.t_dst[t0 + lane] : 0u;
-    for (uint32_t i = 0; i < nt; ++i) {
-        const uint32_t zb = __builtin_amdgcn_readlane(my_beg, i);
-        const uint32_t ze = __builtin_amdgcn_readlane(my_beg, i + 1);
-        const uint32_t dst = __builtin_amdgcn_readlane(my_dst, i);
-        float4 acc = {0.f, 0.f, 0.f, 0.f};
-        uint32_t z = zb;
-        for (; z + S * U <= ze; z += S * U)  // every record of the block exists
-            steps<U, S, OFF32, false>(acc, rec, Bb, z, ze, slot, lane_off, row_bytes);
-        // 0..U steps left (U when the last one is partial), the last one predicated per lane
-        tail_steps<U, S, OFF32>((ze - z + S - 1) / S, acc, rec, Bb, z, ze, slot, lane_off, row_bytes);
-        // combine the S slots (they hold disjoint nonzeros of the same row)
-#pragma unroll
-        for (int off = G; off < 64; off <<= 1) {
-            acc.x += __shfl_xor(acc.x, off);
-            acc.y += __shfl_xor(acc.y, off);
-            acc.z += __shfl_xor(acc.z, off);
-            acc.w += __shfl_xor(acc.w, off);
-        }
-        if (slot == 0 && col_ok) {
-            if (dst & kPartialFlag) {
-                float4 *o = reinterpret_cast<float4 *>(p.partial + static_cast<uint64_t>(dst & ~kPartialFlag) * k + c0);
-                *o = acc;
-            } else {
-                v4f *o = reinterpret_cast<v4f *>(C + static_cast<uint64_t>(dst) * k + c0);
-                const v4f val = {acc.x, acc.y, acc.z, acc.w};
-                __builtin_nontemporal_store(val, o);
-            }
-        }
-    }
+// x[l] + x[l ^ 32] in every lane.  v_permlane32_swap exchanges the upper half of its first
+// operand with the lower half of its second; fed (x, x) it yields {lo,lo} and {hi,hi}.
+__device__ __forceinline__ float xor32_sum(float x) {
+    const uint32_t u = __float_as_uint(x);
+    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
 }
 
-// ---------------------------------------------------------------------------
-// Flat-stream kernel (the default).  Rows of GNN graphs are short (median degree
-// < 10), so a per-row loop restarts its load -> gather -> reduce dependency chain
-// every few nonzeros and leaves a wave with 2-3 loads in flight.  Here a wave
-// treats ALL its records as one stream of steps (S records per step; the planner
-// pads every row to a multiple of S with zero-valued records): the records of a
-// window are fetched once, coalesced, into a wave-private LDS slice, then blocks
-// of U gathers are issued back to back regardless of row boundaries, and a
-// wave-uniform scalar check after each step flushes the accumulator when a row
-// ends.  No barriers: the LDS slice is private to the wave.
-// ---------------------------------------------------------------------------
 constexpr int kWindowRecs = 256;  // records staged per wave and window (2 KiB of LDS)
 
-template <int G, bool OFF32, int U>
-__global__ __launch_bounds__(256) void spmm_flat_kernel(PlanView p, const float *__restrict__ B,
-                                                        float *__restrict__ C) {
-    constexpr int S = 64 / G;
-    __shared__ uint2 lds_rec[kWavesPerBlock][kWindowRecs];
-    const int lane = threadIdx.x & 63;
-    const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t cpx = gridDim.x / kXcds;
-    const uint32_t bid = p.xcd_remap ? (blockIdx.x % kXcds) * cpx + (blockIdx.x / kXcds) : blockIdx.x;
-    const uint32_t w = bid * kWavesPerBlock + wib;
-    if (w >= p.n_waves) return;
+[[maybe_unused]] __device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & (kXcds - 1);
+}
 
+// One chunk = tasks [w_task[c], w_task[c+1]) = one contiguous run of the record stream.
+#ifdef FLEX_TRACE
+#define FLEX_STAMP(i)                                                       \
+    do {                                                                    \
+        uint64_t now_;                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        phase[i] += now_ - last_;                                           \
+        last_ = now_;                                                       \
+    } while (0)
+#else
+#define FLEX_STAMP(i) do {} while (0)
+#endif
+
+template <int G, bool OFF32, int U>
+__device__ __forceinline__ void process_chunk(const PlanView &p, uint32_t c, uint2 *my_lds, const char *__restrict__ Bb,
+                                              float *__restrict__ C, int lane, int c0, bool col_ok
+#ifdef FLEX_TRACE
+                                              , uint64_t *phase, uint64_t &last_
+#endif
+) {
+    constexpr int S = 64 / G;
     const int slot = lane / G;
-    const int sub = lane % G;
     const int k = p.k;
-    const int c0 = blockIdx.y * (4 * G) + sub * 4;
-    const bool col_ok = c0 < k;
     const uint32_t lane_off = (col_ok ? c0 : 0) * 4u;
-    const char *Bb = reinterpret_cast<const char *>(B);
     const uint64_t row_bytes = static_cast<uint64_t>(k) * 4u;
     const uint2 *__restrict__ rec = p.rec;
-    uint2 *my_lds = lds_rec[wib];
 
-    const uint32_t t0 = p.w_task[w], t1 = p.w_task[w + 1];
-    const uint32_t nt = t1 - t0;  // <= 63 (planner invariant)
+    // A chunk holds at most 63 tasks (planner invariant): fetch all descriptors with one
+    // coalesced load per array and hand them out with v_readlane, so no row waits on a
+    // dependent descriptor load.
+    // The chunk header carries the record range too, so the record fetch below does not wait
+    // for the task descriptors: header -> {descriptors, records} -> gathers.
+    const uint4 hdr = p.chunk[c];  // {first task, #tasks, first record, end record}
+    const uint32_t t0 = hdr.x, nt = hdr.y, zb = hdr.z, ze = hdr.w;
     const uint32_t my_beg = (static_cast<uint32_t>(lane) <= nt) ? p.t_beg[t0 + lane] : 0u;
     const uint32_t my_dst = (static_cast<uint32_t>(lane) < nt) ? p.t_dst[t0 + lane] : 0u;
-    const uint32_t zb = __builtin_amdgcn_readlane(my_beg, 0);
-    const uint32_t ze = __builtin_amdgcn_readlane(my_beg, nt);
+    FLEX_STAMP(0);  // descriptors
 
     uint32_t ti = 0;                                          // current task
     uint32_t row_end = __builtin_amdgcn_readlane(my_beg, 1);  // where it ends in the record stream
@@ -224,19 +121,29 @@ __global__ __launch_bounds__(256) void spmm_flat_kernel(PlanView p, const float 
         while (ti < nt && row_end == pos) {
             float4 r = acc;
 #pragma unroll
-            for (int off = G; off < 64; off <<= 1) {
+            for (int off = G; off < 32; off <<= 1) {
                 r.x += __shfl_xor(r.x, off);
                 r.y += __shfl_xor(r.y, off);
                 r.z += __shfl_xor(r.z, off);
                 r.w += __shfl_xor(r.w, off);
+            }
+            if constexpr (G <= 32) {  // lanes l and l^32: one v_permlane32_swap per component, no LDS round trip
+                r.x = xor32_sum(r.x);
+                r.y = xor32_sum(r.y);
+                r.z = xor32_sum(r.z);
+                r.w = xor32_sum(r.w);
             }
             const uint32_t dst = __builtin_amdgcn_readlane(my_dst, ti);
             if (slot == 0 && col_ok) {
                 if (dst & kPartialFlag) {
                     *reinterpret_cast<float4 *>(p.partial + static_cast<uint64_t>(dst & ~kPartialFlag) * k + c0) = r;
                 } else {
+#ifdef FLEX_PLAIN_STORE
+                    *reinterpret_cast<float4 *>(C + static_cast<uint64_t>(dst) * k + c0) = r;
+#else
                     const v4f val = {r.x, r.y, r.z, r.w};
                     __builtin_nontemporal_store(val, reinterpret_cast<v4f *>(C + static_cast<uint64_t>(dst) * k + c0));
+#endif
                 }
             }
             acc = {0.f, 0.f, 0.f, 0.f};
@@ -254,6 +161,7 @@ __global__ __launch_bounds__(256) void spmm_flat_kernel(PlanView p, const float 
             const uint32_t idx = i * 64 + lane;
             if (idx < wn) my_lds[idx] = rec[wz + idx];
         }
+        FLEX_STAMP(1);  // records -> LDS
         const uint32_t nsteps = wn / S;  // rows are padded to multiples of S
         for (uint32_t j = 0; j < nsteps; j += U) {
             uint2 r[U];
@@ -262,6 +170,7 @@ __global__ __launch_bounds__(256) void spmm_flat_kernel(PlanView p, const float 
             for (int u = 0; u < U; ++u) r[u] = my_lds[min(j + u, nsteps - 1) * S + slot];
 #pragma unroll
             for (int u = 0; u < U; ++u) b[u] = gather4<OFF32>(Bb, r[u].x, lane_off, row_bytes);
+            FLEX_STAMP(2);  // gathers
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (j + u < nsteps) {  // wave-uniform
@@ -269,8 +178,47 @@ __global__ __launch_bounds__(256) void spmm_flat_kernel(PlanView p, const float 
                     drain(wz + (j + u + 1) * S);
                 }
             }
+            FLEX_STAMP(3);  // fma + row flushes
         }
     }
+}
+
+// G lanes per record, 4 columns per lane; covers k <= 4*G per blockIdx.y tile.
+// One wave per chunk.  The hardware deals consecutive workgroup ids round-robin over the 8
+// XCDs, so workgroup b is given chunk group (b % 8) * cpx + b / 8: XCD x walks the x-th
+// contiguous eighth of the schedule with ONE cursor, and its resident waves form a sliding
+// window over neighbouring rows whose shared B rows stay in that XCD's 4 MiB L2.  (A
+// persistent variant with per-XCD ticket queues was measured and rejected: DESIGN.md 3.4.)
+template <int G, bool OFF32, int U>
+__global__ __launch_bounds__(256) void spmm_flat_kernel(PlanView p, const float *__restrict__ B,
+                                                        float *__restrict__ C) {
+    __shared__ uint2 lds_rec[kWavesPerBlock][kWindowRecs];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t cpx = gridDim.x / kXcds;  // gridDim.x % 8 == 0
+    const uint32_t bid = p.xcd_remap ? (blockIdx.x % kXcds) * cpx + (blockIdx.x / kXcds) : blockIdx.x;
+    const uint32_t chunk = bid * kWavesPerBlock + wib;
+    if (chunk >= p.n_chunks) return;
+    const int c0 = blockIdx.y * (4 * G) + (lane % G) * 4;  // first of this lane's 4 columns
+    const bool col_ok = c0 < p.k;                            // k % 4 == 0 on this path
+#ifdef FLEX_TRACE  // diagnostic build only (tools/trace.py)
+    const uint64_t trace_t0 = __builtin_amdgcn_s_memrealtime();
+    uint64_t phase[5] = {0, 0, 0, 0, 0};
+    uint64_t last_ = trace_t0;
+    process_chunk<G, OFF32, U>(p, chunk, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok, phase, last_);
+    if (lane == 0 && p.trace != nullptr) {
+        uint64_t *log = p.trace + static_cast<uint64_t>(chunk) * 12;
+        log[0] = xcc_id();
+        log[1] = trace_t0;
+        log[2] = __builtin_amdgcn_s_memrealtime();
+        log[3] = p.chunk[chunk].w - p.chunk[chunk].z;
+        log[4] = 1;
+        log[5] = blockIdx.x % kXcds;
+        for (int i = 0; i < 5; ++i) log[6 + i] = phase[i];
+    }
+#else
+    process_chunk<G, OFF32, U>(p, chunk, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok);
+#endif
 }
 
 // Any k (k % 4 != 0 or unaligned B/C): one wave per task, lane owns columns
@@ -283,11 +231,11 @@ __global__ __launch_bounds__(256) void spmm_generic_kernel(PlanView p, const flo
     const uint32_t cpx = gridDim.x / kXcds;
     const uint32_t bid = p.xcd_remap ? (blockIdx.x % kXcds) * cpx + (blockIdx.x / kXcds) : blockIdx.x;
     const uint32_t w = bid * kWavesPerBlock + wib;
-    if (w >= p.n_waves) return;
+    if (w >= p.n_chunks) return;
     const int k = p.k;
     const int cb = blockIdx.y * 256 + lane;
     const uint2 *__restrict__ rec = p.rec;
-    const uint32_t t0 = p.w_task[w], t1 = p.w_task[w + 1];
+    const uint32_t t0 = p.chunk[w].x, t1 = t0 + p.chunk[w].y;
     for (uint32_t t = t0; t < t1; ++t) {
         const uint32_t zb = p.t_beg[t], ze = p.t_beg[t + 1];
         const uint32_t dst = p.t_dst[t];
@@ -349,14 +297,12 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(float *__restrict__ ds
 
 template <int G, bool OFF32, int U>
 int launch_v4(const PlanView &v, const float *dB, float *dC, hipStream_t s) {
-    uint32_t nblk = (v.n_waves + kWavesPerBlock - 1) / kWavesPerBlock;
+    // persistent grid: enough workgroups to fill every CU (8 x 256 threads each), fewer for tiny plans;
+    // surplus workgroups find the queues empty and leave at once
+    uint32_t nblk = (v.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
     nblk = (nblk + kXcds - 1) / kXcds * kXcds;
     const uint32_t ktiles = (v.k + 4 * G - 1) / (4 * G);
-    // lds_extra: unused dynamic LDS that only lowers the number of resident workgroups per CU
-    if (v.variant == 1)
-        hipLaunchKernelGGL((spmm_v4_kernel<G, OFF32, (U > 4 ? 8 : 4)>), dim3(nblk, ktiles), dim3(256), v.lds_extra, s, v, dB, dC);
-    else
-        hipLaunchKernelGGL((spmm_flat_kernel<G, OFF32, U>), dim3(nblk, ktiles), dim3(256), v.lds_extra, s, v, dB, dC);
+    hipLaunchKernelGGL((spmm_flat_kernel<G, OFF32, U>), dim3(nblk, ktiles), dim3(256), v.lds_extra, s, v, dB, dC);
     FLEX_HIP_TRY(hipGetLastError());
     return FLEX_OK;
 }
@@ -370,9 +316,9 @@ int launch_v4_off(const PlanView &v, bool off32, const float *dB, float *dC, hip
 
 int launch_spmm(const PlanView &v, int lanes_per_nz, bool off32, bool vec4, const float *dB, float *dC,
                 hipStream_t s) {
-    if (v.n_waves == 0) return FLEX_OK;
+    if (v.n_chunks == 0) return FLEX_OK;
     if (!vec4) {
-        uint32_t nblk = (v.n_waves + kWavesPerBlock - 1) / kWavesPerBlock;
+        uint32_t nblk = (v.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
         nblk = (nblk + kXcds - 1) / kXcds * kXcds;
         const uint32_t ktiles = (v.k + 255) / 256;
         if (off32)

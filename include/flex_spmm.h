@@ -97,8 +97,8 @@ int flex_plan_destroy(flex_plan *plan);
 typedef struct flex_plan_info {
     int32_t m, n, k, device;
     int64_t nnz;
-    int64_t n_tasks;      /* wave tasks (rows + chunks of split rows) */
-    int64_t n_waves;      /* waves launched by the main kernel */
+    int64_t n_tasks;      /* tasks: rows + pieces of split rows */
+    int64_t n_chunks;     /* schedule chunks (runs of tasks) that the persistent waves pull from the queues */
     int64_t n_split_rows; /* rows long enough to be split over several waves */
     int64_t n_partials;   /* k-wide partial sums held in the workspace */
     int64_t device_bytes; /* HBM held by the plan */

@@ -67,7 +67,7 @@ def main():
                 us = min(v)
                 i = plans[key].info()
                 print(f"{name:8s} k={k:4d} wave_nnz={key[0]:5d} order={('nat','rcm','clu')[key[1]]} remap={'on' if key[2]==1 else 'off'} kern={'flat' if key[3]==1 else 'row'} ldsx={key[4]:6d} "
-                      f"waves={i['n_waves']:7d} split={i['n_split_rows']:6d} t={us:9.1f}us med={np.median(v):9.1f} "
+                      f"chunks={i['n_chunks']:7d} split={i['n_split_rows']:6d} t={us:9.1f}us med={np.median(v):9.1f} "
                       f"GFLOPS={2*a.nnz*k/us/1e3:9.1f} Balg={balg/us/1e3:8.1f}GB/s gather={a.nnz*k*4/us/1e3:8.1f}GB/s", flush=True)
             for p in plans.values():
                 p.destroy()
