@@ -65,13 +65,8 @@ def main():
     k = args.k
     scale = world if args.scaling == "weak" else 1
     # ---- workload: synthetic graph with the README's shape (x N vertices and nonzeros when weak-scaling)
-    n0, nnz0, alpha, comm, p_in, p_near, win, gcn = flex_amd.SYNTH_PRESETS[args.workload]
-    if (nnz0 - n0) % 2:
-        nnz0 -= 1
     t_gen = time.perf_counter()
-    a = flex_amd.synth_graph(n=n0 * scale, nnz=nnz0 * scale, alpha=alpha, community=comm, p_in=p_in,
-                             p_near=p_near, near_window=win, gcn_norm=bool(gcn), shuffle=bool(args.shuffle),
-                             seed=0xF1E0 + sorted(flex_amd.SYNTH_PRESETS).index(args.workload))
+    a = flex_amd.synth_graph(args.workload, scale=scale, shuffle=bool(args.shuffle))
     t_gen = time.perf_counter() - t_gen
 
     # ---- plan: RCM is a schedule (N=1) or an explicit permutation followed by row sharding (N>1)

@@ -21,6 +21,8 @@ from .binding import (  # noqa: F401
     lib_path,
     order_rcm,
     order_cluster,
+    order_deg,
+    synth_preset,
     perm_csr,
     shard_rows,
     synth_graph,

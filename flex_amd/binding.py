@@ -61,7 +61,7 @@ SYMBOLS = [
     "flex_plan_create", "flex_plan_create_mapped", "flex_plan_create_rows", "flex_spmm",
     "flex_plan_destroy", "flex_plan_get_info", "flex_gather_rows", "flex_csv_load",
     "flex_host_csr_free", "flex_fill_dense_rand", "flex_order_rcm", "flex_order_cluster", "flex_perm_csr",
-    "flex_shard_rows", "flex_synth_graph", "flex_strerror", "flex_last_hip_error",
+    "flex_order_deg", "flex_shard_rows", "flex_synth_graph", "flex_synth_preset", "flex_strerror", "flex_last_hip_error",
     "flex_last_hip_error_string", "flex_abi_version",
 ]
 
@@ -109,6 +109,8 @@ def lib():
         L.flex_fill_dense_rand.argtypes = [vp, i64, i32]
         L.flex_order_rcm.argtypes = [C.POINTER(_Csr), vp]
         L.flex_order_cluster.argtypes = [C.POINTER(_Csr), vp]
+        L.flex_order_deg.argtypes = [C.POINTER(_Csr), i32, vp]
+        L.flex_synth_preset.argtypes = [C.c_char_p, i32, C.POINTER(_SynthParams)]
         L.flex_perm_csr.argtypes = [C.POINTER(_Csr), vp, vp, vp, vp, vp]
         L.flex_shard_rows.argtypes = [C.POINTER(_Csr), i32, i32, vp]
         L.flex_synth_graph.argtypes = [C.POINTER(_SynthParams), C.POINTER(_HostCsr)]
@@ -207,38 +209,34 @@ def shard_rows(a: HostCsr, k: int, nparts: int) -> np.ndarray:
     return bounds
 
 
-# Stand-ins for the graphs of README.md:13-20 (exact n and nnz; structure is synthetic).
-SYNTH_PRESETS = {
-    #            n         nnz        alpha community p_in p_near window gcn_norm
-    "pubmed": (19717, 108365 - 0, 2.6, 64, 0.6, 0.25, 8, 1),  # nnz-n must be even: adjusted below
-    "flickr": (89250, 989006, 2.3, 256, 0.55, 0.25, 8, 1),
-    "ppi": (14755, 458973 - 0, 2.4, 128, 0.6, 0.2, 8, 1),
-    "yelp": (716847, 13954819 - 0, 2.2, 512, 0.55, 0.25, 8, 1),
-    "reddit": (232965, 23446803, 2.1, 2048, 0.6, 0.25, 8, 1),
-    "amazon": (1569960, 264339468, 2.1, 4096, 0.6, 0.25, 8, 0),
-    # SuiteSparse stand-ins fetched by data/SuiteSparse/prepare_mtx_data.sh (shapes from SURVEY 8(d))
-    "wiki-vote": (8297, 103689 - 0, 2.2, 0, 0.0, 0.0, 8, 1),
-    "soc-sign-epinions": (131828, 841372, 2.2, 128, 0.4, 0.2, 8, 1),
-}
+SYNTH_PRESETS = ("amazon", "flickr", "ppi", "pubmed", "reddit", "soc-sign-epinions", "wiki-vote", "yelp")
 
 
-def synth_graph(name: str | None = None, *, n=None, nnz=None, alpha=2.1, community=0, p_in=0.0,
-                p_near=0.0, near_window=8, shuffle=True, gcn_norm=True, seed=None) -> HostCsr:
+def synth_preset(name: str, scale: int = 1) -> _SynthParams:
+    """Generator parameters of the stand-in for a README / SuiteSparse graph (flex_synth_preset)."""
+    p = _SynthParams()
+    _check(lib().flex_synth_preset(name.lower().encode(), int(scale), C.byref(p)), f"flex_synth_preset({name})")
+    return p
+
+
+def synth_graph(name: str | None = None, *, scale: int = 1, n=None, nnz=None, alpha=2.1, community=0, p_in=0.0,
+                p_near=0.0, near_window=8, shuffle=True, gcn_norm=True, seed=0xF1E0) -> HostCsr:
     if name is not None:
-        key = name.lower()
-        n, nnz, alpha, community, p_in, p_near, near_window, gcn = SYNTH_PRESETS[key]
-        gcn_norm = bool(gcn)
-        if (nnz - n) % 2:  # symmetric + one self loop per row needs nnz-n even
-            nnz -= 1
-        if seed is None:
-            seed = 0xF1E0 + sorted(SYNTH_PRESETS).index(key)
-    if seed is None:
-        seed = 0xF1E0
-    p = _SynthParams(int(n), int(nnz), float(alpha), int(community), float(p_in), float(p_near),
-                     int(near_window), int(bool(shuffle)), int(bool(gcn_norm)), int(seed))
+        p = synth_preset(name, scale)
+        p.shuffle = int(bool(shuffle))
+    else:
+        p = _SynthParams(int(n), int(nnz), float(alpha), int(community), float(p_in), float(p_near),
+                         int(near_window), int(bool(shuffle)), int(bool(gcn_norm)), int(seed))
     s = _HostCsr()
     _check(lib().flex_synth_graph(C.byref(p), C.byref(s)), f"flex_synth_graph({name or n})")
     return _take(s)
+
+
+def order_deg(a: HostCsr, descending: bool = True) -> np.ndarray:
+    rank = np.empty(max(a.m, 1), dtype=np.uint32)
+    v = a.view()
+    _check(lib().flex_order_deg(C.byref(v), int(descending), rank.ctypes.data), "flex_order_deg")
+    return rank[: a.m]
 
 
 class Plan:

@@ -1,0 +1,16 @@
+// flex.h (host mirror) -- ≙ flex.cuh:59-60: the two entry points main() uses.
+#pragma once
+#include "DataLoader.h"
+#include "Mat.h"
+
+struct RunOptions {
+    int warmup = 5, iters = 10;  // the reference's vendor protocol, flex.cu:5766-5789
+    bool json = false;           // one JSON line per configuration instead of the table only
+    bool vendor = true;          // run hipSPARSE as gold + baseline (false: CPU-free self check only)
+};
+RunOptions &run_options();
+
+void run(DataLoader &input);                      // ≙ flex.cu:4560-5716: bench loop over orderings
+void cuSpmm(DataLoader &input, Perfs &perfRes);   // ≙ flex.cu:5717-5804: vendor SpMM (hipSPARSE) -> input.gpuC
+// ≙ resCheck, flex.cu:4154-4213; returns the number of elements beyond 4*eps*row_nnz
+int resCheck(const float *h_gold, float *h_res, const Mat &mat, Perfs &perfRes, double *max_err_out = nullptr);

@@ -1,0 +1,174 @@
+// run.cpp (host mirror) -- ≙ run / cuSpmm / resCheck of flex.cu (4560-5716, 5717-5804,
+// 4154-4213).  Same loop shape -- vendor gold first, then one (ordering x schedule) configuration
+// after another: plan, launch_prep, warm-up, timed launches, copy back, resCheck, free -- with
+// NPerf/pTable replaced by HIP events and printf, and GFLOP/s = 2e-9*nnz*k/t (flex.cu:5629).
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "../../../include/flex_vendor.h"
+#include "flex.h"
+
+RunOptions &run_options() {
+    static RunOptions o;
+    return o;
+}
+
+void cuSpmm(DataLoader &input, Perfs &perfRes) {
+    hipEvent_t e0, e1, e2, e3;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    HIP_CHECK(hipEventCreate(&e2));
+    HIP_CHECK(hipEventCreate(&e3));
+    flex_vendor *h = nullptr;
+    HIP_CHECK(hipEventRecord(e0, nullptr));
+    const int rc = flex_vendor_spmm_create(&h, static_cast<int32_t>(input.m), static_cast<int32_t>(input.n),
+                                           static_cast<int64_t>(input.nnz), input.rowPtr_dev, input.col_dev,
+                                           input.vals_dev, static_cast<int>(input.dim), input.gpuX, input.gpuC);
+    if (rc) {  // the reference's CHECK_CUSPARSE only prints (common.h:81-90); a missing gold is fatal here
+        std::printf("hipSPARSE API failed: code %d status %d\n", rc, flex_vendor_last_status());
+        throw std::runtime_error("hipSPARSE SpMM setup failed");
+    }
+    HIP_CHECK(hipEventRecord(e1, nullptr));
+    for (int i = 0; i < 5; ++i) flex_vendor_spmm_run(h, nullptr);  // warm-up, flex.cu:5766-5773
+    HIP_CHECK(hipEventRecord(e2, nullptr));
+    for (int i = 0; i < 10; ++i) flex_vendor_spmm_run(h, nullptr);
+    HIP_CHECK(hipEventRecord(e3, nullptr));
+    HIP_CHECK(hipEventSynchronize(e3));
+    float setup_ms = 0, proc_ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&setup_ms, e0, e1));
+    HIP_CHECK(hipEventElapsedTime(&proc_ms, e2, e3));
+    perfRes.cuSpmmSetup = setup_ms * 1e3f;
+    perfRes.cuSpmmProcessing = proc_ms * 1e3f / 10;  // microseconds per SpMM
+    perfRes.cuSpmm_time = perfRes.cuSpmmSetup + perfRes.cuSpmmProcessing;
+    flex_vendor_spmm_destroy(h);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipEventDestroy(e2);
+    (void)hipEventDestroy(e3);
+}
+
+int resCheck(const float *h_gold, float *h_res, const Mat &mat, Perfs &perfRes, double *max_err_out) {
+    const int m = mat.m, k = mat.k;
+    int count = 0, err_show_remaining = 20, nz = 0, me_nnz = 0, last_err_row = -1;
+    double max_err = 0;
+    const auto &rp = mat.dl.dl_original->rowPtr;  // tolerance uses the ORIGINAL order's row lengths (flex.cu:4170)
+    for (int r = 0; r < m; ++r) {
+        const int row_nnz = static_cast<int>(rp[r + 1] - rp[r]);
+        const double tol = static_cast<double>(FLT_EPSILON) * row_nnz * 4;
+        for (int c = 0; c < k; ++c) {
+            const size_t idx = static_cast<size_t>(r) * k + c;
+            if (h_gold[idx] == 0) nz++;
+            const double err = std::fabs(h_gold[idx]) < 1 ? std::fabs(double(h_gold[idx]) - h_res[idx])
+                                                          : std::fabs(1.0 - double(h_res[idx]) / h_gold[idx]);
+            if (err > max_err) {
+                max_err = err;
+                me_nnz = row_nnz;
+            }
+            if (err > tol || err != err) {
+                count++;
+                if (r != last_err_row && err_show_remaining-- > 0) {
+                    last_err_row = r;
+                    std::printf(" ref[%d][%d]:  %f!=%f (correct)  %d nnzs, dif %g, tol %g\n", r, c, h_res[idx],
+                                h_gold[idx], row_nnz, err, tol);
+                }
+            }
+        }
+    }
+    perfRes.flex_spmm_errors.push_back(count);
+    if (count) std::printf("Kernel errs: %d Max err %g at nnz=%d.\n", count, max_err, me_nnz);
+    if (nz >= m * k / 2) std::printf("warning: gold is mostly zeros (%d of %d), errors are hard to catch\n", nz, m * k);
+    if (max_err_out) *max_err_out = max_err;
+    std::memset(h_res, 0, sizeof(float) * static_cast<size_t>(m) * k);
+    return count;
+}
+
+namespace {
+
+struct Row {
+    std::string ord, sched;
+    double t_us, gflops, balg_gbs, plan_ms, max_err;
+    int errs;
+    flex_plan_info info;
+};
+
+void bench_one(DataLoader &dl, unsigned schedule, const char *sched_name, const DataLoader &gold_src, float *h_res,
+               Perfs &perfRes, std::vector<Row> &rows) {
+    const RunOptions &o = run_options();
+    Mat mat(dl, 0, 0);
+    mat.schedule = schedule;
+    mat.csr2_DiagTiling();
+    mat.alpha_transfer();
+    mat.launch_prep();
+    hipEvent_t e0, e1;
+    HIP_CHECK(hipEventCreate(&e0));
+    HIP_CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < o.warmup; ++i) mat.launch();
+    HIP_CHECK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < o.iters; ++i) mat.launch();
+    HIP_CHECK(hipEventRecord(e1, nullptr));
+    HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    const double t_us = ms * 1e3 / o.iters;
+    HIP_CHECK(hipMemcpy(h_res, mat.mat_c_dev, dl.gpuC_bytes, hipMemcpyDeviceToHost));
+    double max_err = 0;
+    int errs = -1;
+    if (!gold_src.h_ref_c.empty()) errs = resCheck(gold_src.h_ref_c.data(), h_res, mat, perfRes, &max_err);
+    const double flops = 2.0 * dl.nnz * dl.dim;
+    const double balg = (double(dl.n) + 1 + 2.0 * dl.nnz + 2.0 * dl.n * dl.dim) * 4;  // flex.cu:4672, 5795
+    rows.push_back({dl.vertex_order_abbr, sched_name, t_us, flops / t_us * 1e-3, balg / t_us * 1e-3,
+                    mat.info().plan_ms, max_err, errs, mat.info()});
+    perfRes.flex_spmm_time.push_back(static_cast<float>(t_us * 1e-3));
+    mat.alpha_freeMatGPU();
+}
+
+}  // namespace
+
+void run(DataLoader &input_vo) {
+    const RunOptions &o = run_options();
+    Perfs perfRes;
+    if (o.vendor) input_vo.c_cuSpmm_run(perfRes);  // gold + vendor baseline (flex.cu:4569)
+    std::unique_ptr<float[]> h_res(new float[std::max<int64_t>(input_vo.C_elts, 1)]);
+    std::vector<Row> rows;
+
+    // engine-side schedules on the original loader (no permuted CSR, no permuteX pass)
+    bench_one(input_vo, FLEX_ORDER_NATURAL, "natural", input_vo, h_res.get(), perfRes, rows);
+    bench_one(input_vo, FLEX_ORDER_RCM, "rcm", input_vo, h_res.get(), perfRes, rows);
+    bench_one(input_vo, FLEX_ORDER_CLUSTER, "cluster", input_vo, h_res.get(), perfRes, rows);
+    // the reference's flow: reordered loaders (flex.cu:4572-4576), plan folds vo_mp back in
+    {
+        DataLoaderRcm rcm(input_vo);
+        bench_one(rcm, FLEX_ORDER_NATURAL, "natural", input_vo, h_res.get(), perfRes, rows);
+    }
+    {
+        DataLoaderRabbit rbt(input_vo);
+        bench_one(rbt, FLEX_ORDER_NATURAL, "natural", input_vo, h_res.get(), perfRes, rows);
+    }
+    {
+        DataLoaderDeg deg(input_vo);
+        bench_one(deg, FLEX_ORDER_NATURAL, "natural", input_vo, h_res.get(), perfRes, rows);
+    }
+
+    const double flops = 2.0 * input_vo.nnz * input_vo.dim;
+    if (o.vendor)
+        std::printf("hipSPARSE setup/us: %.2f , processing/us: %.2f  (%.1f GFLOP/s)\n", perfRes.cuSpmmSetup,
+                    perfRes.cuSpmmProcessing, flops / perfRes.cuSpmmProcessing * 1e-3);
+    std::printf("%-4s %-8s %10s %10s %10s %8s %8s %8s %8s %9s\n", "Ord", "sched", "t/us", "GFLOP/s", "Balg GB/s",
+                "%8TB/s", "chunks", "split", "plan/ms", "errs");
+    for (const Row &r : rows) {
+        std::printf("%-4s %-8s %10.1f %10.1f %10.1f %8.2f %8lld %8lld %8.1f %9d\n", r.ord.c_str(), r.sched.c_str(),
+                    r.t_us, r.gflops, r.balg_gbs, r.balg_gbs / 8000.0 * 100, static_cast<long long>(r.info.n_chunks),
+                    static_cast<long long>(r.info.n_split_rows), r.plan_ms, r.errs);
+        if (o.json)
+            std::printf("{\"graph\":\"%s\",\"n\":%zu,\"nnz\":%zu,\"k\":%zu,\"ord\":\"%s\",\"schedule\":\"%s\",\"t_us\":%.3f,"
+                        "\"gflops\":%.2f,\"balg_gbs\":%.2f,\"max_err\":%.3g,\"errs\":%d,\"vendor_us\":%.3f}\n",
+                        input_vo.graph_name.c_str(), input_vo.n, input_vo.nnz, input_vo.dim, r.ord.c_str(),
+                        r.sched.c_str(), r.t_us, r.gflops, r.balg_gbs, r.max_err, r.errs, perfRes.cuSpmmProcessing);
+    }
+    for (const Row &r : rows)
+        if (r.errs > 0) throw std::runtime_error("resCheck failed");  // ≙ assert(!count), flex.cu:4205
+}

@@ -95,6 +95,23 @@ int flex_order_rcm(const flex_csr *A, uint32_t *rank) {
     return FLEX_OK;
 }
 
+int flex_order_deg(const flex_csr *A, int descending, uint32_t *rank) {
+    if (!rank) return FLEX_ERR_INVALID;
+    int rc = flex::validate_csr(A);
+    if (rc) return rc;
+    if (A->m != A->n) return FLEX_ERR_INVALID;
+    const int32_t n = A->m;
+    std::vector<uint32_t> deg(static_cast<size_t>(n), 0u), by(static_cast<size_t>(n));
+    for (int32_t u = 0; u < n; ++u) deg[u] = A->rowPtr[u + 1] - A->rowPtr[u];
+    for (int64_t e = 0; e < A->nnz; ++e) ++deg[A->col[e]];
+    std::iota(by.begin(), by.end(), 0u);
+    std::stable_sort(by.begin(), by.end(), [&](uint32_t a, uint32_t b) {
+        return descending ? deg[a] > deg[b] : deg[a] < deg[b];
+    });
+    for (int32_t i = 0; i < n; ++i) rank[by[i]] = static_cast<uint32_t>(i);
+    return FLEX_OK;
+}
+
 int flex_perm_csr(const flex_csr *A, const uint32_t *rank, int32_t *vo_mp, uint32_t *rowPtr2, uint32_t *col2,
                   float *vals2) {
     if (!rank || !vo_mp || !rowPtr2 || (A && A->nnz > 0 && (!col2 || !vals2))) return FLEX_ERR_INVALID;

@@ -89,6 +89,40 @@ void sort_unique(std::vector<uint64_t> &keys, uint64_t n) {
 
 }  // namespace
 
+extern "C" int flex_synth_preset(const char *name, int scale, flex_synth_params *out) {
+    if (!name || !out || scale < 1) return FLEX_ERR_INVALID;
+    struct Preset {
+        const char *name;
+        int64_t n, nnz;
+        double alpha;
+        int64_t community;
+        double p_in, p_near;
+        int gcn;
+    };
+    // shapes: README.md:13-20 (GNN graphs) and SURVEY 8(d) (the two SuiteSparse matrices that
+    // data/SuiteSparse/prepare_mtx_data.sh fetches); structure parameters are this project's choice
+    static const Preset table[] = {
+        {"amazon", 1569960, 264339468, 2.1, 4096, 0.60, 0.25, 0},
+        {"flickr", 89250, 989006, 2.3, 256, 0.55, 0.25, 1},
+        {"ppi", 14755, 458973, 2.4, 128, 0.60, 0.20, 1},
+        {"pubmed", 19717, 108365, 2.6, 64, 0.60, 0.25, 1},
+        {"reddit", 232965, 23446803, 2.1, 2048, 0.60, 0.25, 1},
+        {"soc-sign-epinions", 131828, 841372, 2.2, 128, 0.40, 0.20, 1},
+        {"wiki-vote", 8297, 103689, 2.2, 0, 0.0, 0.0, 1},
+        {"yelp", 716847, 13954819, 2.2, 512, 0.55, 0.25, 1},
+    };
+    for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
+        if (std::strcmp(name, table[i].name) != 0) continue;
+        const Preset &t = table[i];
+        int64_t nnz = t.nnz;
+        if ((nnz - t.n) & 1) --nnz;  // symmetric + one self loop per row needs nnz - n even
+        *out = flex_synth_params{t.n * scale, nnz * scale, t.alpha, t.community, t.p_in, t.p_near, 8, 1, t.gcn,
+                                 0xF1E0ull + i};
+        return FLEX_OK;
+    }
+    return FLEX_ERR_INVALID;
+}
+
 extern "C" int flex_synth_graph(const flex_synth_params *p, flex_host_csr *out) {
     if (!p || !out) return FLEX_ERR_INVALID;
     std::memset(out, 0, sizeof *out);

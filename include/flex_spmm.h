@@ -141,6 +141,9 @@ int flex_fill_dense_rand(float *hostB, int64_t n, int k);
 /* ≙ order_rcm(h) (order_rcm.cu:15-33): rank[old] = new. */
 int flex_order_rcm(const flex_csr *A, uint32_t *rank);
 
+/* ≙ order_deg(h, desc) (order_deg.cu:19-45): rank by in+out degree, ties by vertex id. */
+int flex_order_deg(const flex_csr *A, int descending, uint32_t *rank);
+
 /* ≙ the clustering half of DataLoaderRabbit (DataLoader.cu:453-655): rank[old] = new such
  * that communities (and their sub-communities) are consecutive. */
 int flex_order_cluster(const flex_csr *A, uint32_t *rank);
@@ -172,6 +175,10 @@ typedef struct flex_synth_params {
     uint64_t seed;
 } flex_synth_params;
 int flex_synth_graph(const flex_synth_params *p, flex_host_csr *out);
+/* Parameters of the stand-in for a named graph of the README / the SuiteSparse sweep
+ * ("pubmed","flickr","reddit","ppi","yelp","amazon","wiki-vote","soc-sign-epinions"),
+ * scaled to `scale` x vertices and nonzeros (weak-scaling runs). */
+int flex_synth_preset(const char *name, int scale, flex_synth_params *out);
 
 const char *flex_strerror(int status);
 /* hipError_t of the last failed HIP call on this thread (0 if none) and its text. */

@@ -227,3 +227,44 @@ def test_large_properties_checksum_and_linearity():
         v = a.vals[a.rowPtr[r]:a.rowPtr[r + 1]]
         ref = (v[:, None].astype(np.float64) * B1h[cols]).sum(axis=0)
         assert np.all(np.abs(C1[r] - ref) <= 4 * np.finfo(np.float32).eps * len(cols) * np.maximum(1, np.abs(ref)))
+
+
+def test_cxx_host_mirror_cli_pubmed_and_amat():
+    """The C++ DataLoader/Mat/run mirror (flex_amd/lib/flex): hipSPARSE gold + resCheck, every
+    ordering must report zero mismatches (≙ assert(!count), flex.cu:4205)."""
+    import json
+    import subprocess
+    exe = os.path.join(os.path.dirname(flex_amd.lib_path()), "flex")
+    assert os.path.exists(exe)
+    for path, k in ((os.path.join(GOLDEN, "pubmed.csv"), "32"), (os.path.join(GOLDEN, "a_mat.csv"), "8")):
+        out = subprocess.run([exe, path, k, "--json"], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        rows = [json.loads(line) for line in out.stdout.splitlines() if line.startswith("{")]
+        assert {(r["ord"], r["schedule"]) for r in rows} >= {("OVO", "natural"), ("OVO", "cluster"), ("RCM", "natural"),
+                                                             ("RBT", "natural"), ("DEG", "natural")}
+        assert all(r["errs"] == 0 for r in rows)
+    assert "hipSPARSE setup" in out.stdout
+
+
+def test_vendor_baseline_matches_oracle():
+    """libflex_vendor.so (hipSPARSE CSR_ALG3, row-major) is the reference's gold (cuSpmm,
+    flex.cu:5717-5804): check it against the CPU oracle too."""
+    import ctypes as C
+    a = flex_amd.csv_load(os.path.join(GOLDEN, "pubmed.csv"))
+    k = 32
+    B = oracle.gen_B(a.n, k)
+    V = C.CDLL(os.path.join(os.path.dirname(flex_amd.lib_path()), "libflex_vendor.so"))
+    V.flex_vendor_spmm_create.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int64, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    V.flex_vendor_spmm_run.argtypes = [C.c_void_p, C.c_void_p]
+    V.flex_vendor_spmm_destroy.argtypes = [C.c_void_p]
+    rp, col, val = dev(a.rowPtr.astype(np.int32)), dev(a.col.astype(np.int32)), dev(a.vals)
+    Bd = dev(B)
+    Cd = torch.zeros((a.m, k), device="cuda")
+    h = C.c_void_p()
+    assert V.flex_vendor_spmm_create(C.byref(h), a.m, a.n, a.nnz, rp.data_ptr(), col.data_ptr(), val.data_ptr(), k,
+                                     Bd.data_ptr(), Cd.data_ptr()) == 0
+    assert V.flex_vendor_spmm_run(h, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    V.flex_vendor_spmm_destroy(h)
+    assert_matches_oracle(a, B, Cd.cpu().numpy())

@@ -35,13 +35,8 @@ def main():
         shuffle = True
         if name.endswith("-noshuf"):
             name, shuffle = name[:-7], False
-        n0, nnz0, alpha, comm, p_in, p_near, win, gcn = flex_amd.SYNTH_PRESETS[name]
-        if (nnz0 - n0) % 2:
-            nnz0 -= 1
         t = time.time()
-        a = flex_amd.synth_graph(n=n0, nnz=nnz0, alpha=alpha, community=comm, p_in=p_in, p_near=p_near,
-                                 near_window=win, gcn_norm=bool(gcn), shuffle=shuffle,
-                                 seed=0xF1E0 + sorted(flex_amd.SYNTH_PRESETS).index(name))
+        a = flex_amd.synth_graph(name, shuffle=shuffle)
         print(f"# {name} shuffle={shuffle} n={a.n} nnz={a.nnz} gen {time.time()-t:.1f}s", flush=True)
         for k in ks:
             B = torch.rand((a.n, k), device="cuda") * 2 - 1
