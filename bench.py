@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--order", default="cluster", choices=["cluster", "rcm", "natural"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--shuffle", type=int, default=1, help="0: keep the generator's planted order (locality upper bound)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + FLEX_BENCH_DEVICE=0 rehearses the N>1 path on a one-GPU box (not a measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="verify rank 0's shard against the oracle (small workloads)")
     return ap.parse_args()
@@ -57,10 +59,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: there is no CPU fallback for the measured path")
+    if "FLEX_BENCH_DEVICE" in os.environ:  # rehearsal only: every rank on one card
+        local_rank = int(os.environ["FLEX_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     k = args.k
     scale = world if args.scaling == "weak" else 1
@@ -76,18 +83,11 @@ def main():
     if world == 1:
         plan = flex_amd.Plan(a, k, device=local_rank, order=order)
         shard_nnz, shard_rows = a.nnz, a.m
-        a_local, vo, r0, r1 = a, None, 0, a.m
+        shard = None
     else:
-        if args.order != "natural":
-            rank = flex_amd.order_rcm(a) if args.order == "rcm" else flex_amd.order_cluster(a)
-            vo, a_local = flex_amd.perm_csr(a, rank)
-        else:
-            vo, a_local = None, a
-        bounds = flex_amd.shard_rows(a_local, k, world)
-        r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
-        plan = flex_amd.Plan(a_local, k, device=local_rank, rows=(r0, r1), col_map=vo)
-        shard_nnz = int(a_local.rowPtr[r1]) - int(a_local.rowPtr[r0])
-        shard_rows = r1 - r0
+        shard = flex_amd.make_shard(a, k, rank, world, order=args.order)
+        plan = shard.plan(k, local_rank)
+        shard_nnz, shard_rows = shard.nnz, shard.r1 - shard.r0
     t_plan = time.perf_counter() - t_plan
     info = plan.info()
 
@@ -104,7 +104,12 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        dist.broadcast(B, src=0)
+        if args.backend == "nccl":
+            flex_amd.broadcast_dense(B, src=0)  # RCCL over xGMI
+        else:
+            Bh = B.cpu()
+            flex_amd.broadcast_dense(Bh, src=0)
+            B.copy_(Bh)
         torch.cuda.synchronize()
         bcast_ms = (time.perf_counter() - t0) * 1e3
     C = torch.empty((shard_rows, k), device=dev, dtype=torch.float32)
@@ -132,7 +137,7 @@ def main():
         dist.barrier()
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream (torch's current stream)
     if world > 1:
-        t = torch.tensor([wall, dev_ms], device=dev, dtype=torch.float64)
+        t = torch.tensor([wall, dev_ms], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(t[0]), float(t[1])
 
@@ -140,13 +145,12 @@ def main():
     if args.check and rank == 0:
         import oracle
         Bh = B.cpu().numpy()
-        rp = a_local.rowPtr[r0:r1 + 1].astype(np.int64)
-        rp0 = rp - rp[0]
-        cols = a_local.col[rp[0]:rp[-1]]
-        if vo is not None:
-            cols = vo[cols].astype(np.uint32)
-        gold = oracle.spmm(rp0.astype(np.uint32), cols, a_local.vals[rp[0]:rp[-1]], Bh, nthreads=os.cpu_count() or 1)
-        cnt, max_err, _, _ = oracle.rescheck(gold, C.cpu().numpy(), rp0.astype(np.uint32))
+        if shard is None:
+            rp0, cols, vals = a.rowPtr, a.col, a.vals
+        else:
+            rp0, cols, vals = shard.local_csr()
+        gold = oracle.spmm(rp0, cols, vals, Bh, nthreads=os.cpu_count() or 1)
+        cnt, max_err, _, _ = oracle.rescheck(gold, C.cpu().numpy(), rp0)
         ok = {"mismatches": cnt, "max_err": max_err}
         if cnt:
             raise SystemExit(f"bench --check: {cnt} mismatches vs oracle")

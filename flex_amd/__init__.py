@@ -28,3 +28,4 @@ from .binding import (  # noqa: F401
     synth_graph,
     SYNTH_PRESETS,
 )
+from .multigpu import RowShard, broadcast_dense, make_shard  # noqa: F401

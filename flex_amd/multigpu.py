@@ -1,0 +1,74 @@
+"""Row sharding of one SpMM over the GPUs of a node (one process per GPU).
+
+New work: the reference is single-GPU (flex.cu:4137).  Rows of A -- and of C -- are
+independent units, B is replicated, so the data path has no collective: B is broadcast ONCE
+(RCCL over xGMI via torch.distributed) before the timed region and every rank then runs
+flex_spmm on its own contiguous, cost-balanced slice of the (re-ordered) rows.
+
+Host logic only (numpy + torch.distributed); the per-rank compute is a flex_amd.Plan.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import binding as _b
+
+
+@dataclass
+class RowShard:
+    a: "_b.HostCsr"         # the (re-ordered) matrix all ranks agree on
+    vo_mp: np.ndarray | None  # vo_mp[new] = old when a was re-ordered, else None
+    bounds: np.ndarray      # world+1 row boundaries in a's row order
+    rank: int
+    world: int
+
+    @property
+    def r0(self) -> int:
+        return int(self.bounds[self.rank])
+
+    @property
+    def r1(self) -> int:
+        return int(self.bounds[self.rank + 1])
+
+    @property
+    def nnz(self) -> int:
+        return int(self.a.rowPtr[self.r1]) - int(self.a.rowPtr[self.r0])
+
+    def plan(self, k: int, device: int) -> "_b.Plan":
+        """Plan for this rank's rows; columns are mapped back through vo_mp so the un-permuted B is used."""
+        return _b.Plan(self.a, k, device=device, rows=(self.r0, self.r1), col_map=self.vo_mp)
+
+    def local_csr(self):
+        """(rowPtr, col, vals) of this rank's slice with columns in ORIGINAL numbering (what the plan computes)."""
+        rp = self.a.rowPtr[self.r0:self.r1 + 1].astype(np.int64)
+        cols = self.a.col[rp[0]:rp[-1]]
+        if self.vo_mp is not None:
+            cols = self.vo_mp[cols].astype(np.uint32)
+        return (rp - rp[0]).astype(np.uint32), cols, self.a.vals[rp[0]:rp[-1]]
+
+    def original_rows(self) -> np.ndarray:
+        """Original row id of every local row (to scatter the C slice back)."""
+        rows = np.arange(self.r0, self.r1)
+        return rows if self.vo_mp is None else self.vo_mp[rows]
+
+
+def make_shard(a: "_b.HostCsr", k: int, rank: int, world: int, order: str = "cluster") -> RowShard:
+    """Every rank calls this with the same `a`: reorder first (so a shard's columns form a band /
+    a set of communities), then cut contiguous row ranges of equal cost (flex_shard_rows)."""
+    if order == "natural":
+        vo, ap = None, a
+    else:
+        rank_arr = {"rcm": _b.order_rcm, "cluster": _b.order_cluster, "deg": _b.order_deg}[order](a)
+        vo, ap = _b.perm_csr(a, rank_arr)
+    bounds = _b.shard_rows(ap, k, world)
+    return RowShard(ap, vo, bounds, rank, world)
+
+
+def broadcast_dense(B, src: int = 0):
+    """One broadcast of the dense operand; `nccl` (RCCL over xGMI) on GPUs, `gloo` in CPU tests."""
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(B, src=src)
+    return B

@@ -140,8 +140,10 @@ def test_row_shards_concatenate_to_full():
     bounds = flex_amd.shard_rows(a, k, 4)
     assert bounds[0] == 0 and bounds[-1] == a.m and np.all(np.diff(bounds) > 0)
     parts = [run_plan(Plan(a, k, rows=(bounds[i], bounds[i + 1])), B) for i in range(4)]
-    assert np.array_equal(np.concatenate(parts), full)  # same schedule per row -> bit-identical
+    # shards pick their own chunk budget, so a split row may be summed in a different order
+    assert oracle.rescheck(full, np.concatenate(parts), a.rowPtr)[0] == 0
     assert_matches_oracle(a, B, full)
+    assert_matches_oracle(a, B, np.concatenate(parts))
 
 
 def test_unaligned_buffers_take_the_generic_kernel():
