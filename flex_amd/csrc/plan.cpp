@@ -127,7 +127,6 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     const long auto_budget = std::clamp<long>(static_cast<long>(8.0 * avg_deg), 96, 256);
     const uint32_t wave_nnz = static_cast<uint32_t>(env_long("FLEX_WAVE_NNZ", auto_budget));
     const uint32_t row_cost = static_cast<uint32_t>(env_long("FLEX_ROW_COST", 16));
-    const uint32_t long_row = 2 * wave_nnz;
     p->xcd_remap = env_long("FLEX_XCD_REMAP", 1) != 2;  // 2 = off (tuning experiments only)
     p->lds_extra = static_cast<unsigned>(env_long("FLEX_LDS_EXTRA", 1)) & ~15u;  // default 0 (1 -> 0)
     const uint32_t S = 64u / static_cast<uint32_t>(G);      // records per step: rows are padded to it
@@ -163,6 +162,14 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
             wave_cost = 0;
         }
     };
+    // Rows longer than one budget are cut into pieces of one budget, each a chunk of its own that
+    // writes a k-wide partial sum: one wave keeps only U gathers in flight, so a long row is much
+    // faster as several concurrent pieces (flickr, MI355X: 88 us with no splitting, 43 us with
+    // rows > 192 records split, 40 us with rows > 96 split; reddit is flat from 256 to 512;
+    // DESIGN.md 3.3).  Pieces stay in schedule order: moving them to the
+    // front of the XCD slices helped flickr by 3 % and cost reddit 12 % (half its chunks are pieces).
+    const uint32_t long_row = static_cast<uint32_t>(env_long("FLEX_LONG_ROW", wave_nnz));
+    const uint32_t piece = std::max<uint32_t>(S, static_cast<uint32_t>(env_long("FLEX_PIECE", wave_nnz)) / S * S);
     try {
         for (int32_t i = 0; i < m; ++i) {
             const uint32_t r = sched[i];
@@ -170,18 +177,18 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
             const uint32_t len = e1 - e0;
             const uint32_t dst = dst_map ? static_cast<uint32_t>(dst_map[r]) : r - static_cast<uint32_t>(r0);
             if (len > long_row) {
-                const uint32_t nchunk = (len + wave_nnz - 1) / wave_nnz;
+                const uint32_t nchunk = (len + piece - 1) / piece;
                 const uint32_t per = ((len + nchunk - 1) / nchunk + S - 1) / S * S;  // whole steps
                 split.push_back({dst, n_partials, 0});
                 for (uint32_t c0 = e0; c0 < e1; c0 += per) {
                     const uint32_t c1 = std::min(e1, c0 + per);
-                    w_task.push_back(static_cast<uint32_t>(t_dst.size()));  // a chunk is a wave of its own
+                    w_task.push_back(static_cast<uint32_t>(t_dst.size()));  // a piece is a chunk of its own
                     t_beg.push_back(static_cast<uint32_t>(rec.size()));
                     t_dst.push_back(kPartialFlag | n_partials++);
                     emit_records(c0, c1);
                     split.back().count++;
                 }
-                wave_cost = wave_nnz;  // force a fresh wave for the next row
+                wave_cost = wave_nnz;  // the next ordinary row opens a fresh chunk
             } else {
                 open_wave_if_needed();
                 t_beg.push_back(static_cast<uint32_t>(rec.size()));
@@ -207,9 +214,12 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     if ((rc = upload(&p->d_rec, rec, &p->device_bytes))) return rc;
     if ((rc = upload(&p->d_t_beg, t_beg, &p->device_bytes))) return rc;
     if ((rc = upload(&p->d_t_dst, t_dst, &p->device_bytes))) return rc;
-    std::vector<uint4> chunk(p->n_chunks);
-    for (uint32_t c = 0; c < p->n_chunks; ++c)
+    // Chunk table in launch order: the kernel gives XCD x the x-th eighth of it.
+    const uint32_t n_all = static_cast<uint32_t>(w_task.size() - 1);
+    std::vector<uint4> chunk(n_all);
+    for (uint32_t c = 0; c < n_all; ++c)
         chunk[c] = make_uint4(w_task[c], w_task[c + 1] - w_task[c], t_beg[w_task[c]], t_beg[w_task[c + 1]]);
+    p->n_chunks = static_cast<uint32_t>(chunk.size());
     if ((rc = upload(&p->d_chunk, chunk, &p->device_bytes))) return rc;
     if ((rc = upload(&p->d_split, split, &p->device_bytes))) return rc;
     const size_t pbytes = std::max<size_t>(1, static_cast<size_t>(n_partials) * k) * sizeof(float);

@@ -261,7 +261,9 @@ __global__ __launch_bounds__(256) void spmm_generic_kernel(PlanView p, const flo
     }
 }
 
-// C[row,:] = partial[first,:] + partial[first+1,:] + ... in that fixed order.
+// C[row,:] = partial[first,:] + partial[first+1,:] + ... in that fixed order.  Eight pieces are
+// loaded before the first add so the (tiny) kernel costs a couple of memory round trips, not
+// one per piece; the adds stay strictly in piece order, so the result is reproducible.
 __global__ __launch_bounds__(256) void spmm_fixup_kernel(const float *__restrict__ partial,
                                                          const SplitRow *__restrict__ rows, uint32_t n_rows,
                                                          int k, float *__restrict__ C) {
@@ -271,8 +273,22 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const float *__restrict
     if (i >= n_rows) return;
     const SplitRow sr = rows[i];
     for (int c = lane; c < k; c += 64) {
+        const float *p = partial + static_cast<uint64_t>(sr.first) * k + c;
         float s = 0.f;
-        for (uint32_t j = 0; j < sr.count; ++j) s += partial[static_cast<uint64_t>(sr.first + j) * k + c];
+        uint32_t j = 0;
+        for (; j + 8 <= sr.count; j += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[static_cast<uint64_t>(j + u) * k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (j + u < sr.count) ? p[static_cast<uint64_t>(j + u) * k] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (j + u < sr.count) s += v[u];
         C[static_cast<uint64_t>(sr.row) * k + c] = s;
     }
 }
