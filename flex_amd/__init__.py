@@ -10,6 +10,7 @@ from .binding import (  # noqa: F401
     FLEX_ORDER_NATURAL,
     FLEX_ORDER_RCM,
     FLEX_ORDER_CLUSTER,
+    FLEX_ORDER_GORDER,
     FlexError,
     HostCsr,
     Plan,
@@ -22,6 +23,7 @@ from .binding import (  # noqa: F401
     order_rcm,
     order_cluster,
     order_deg,
+    order_gorder,
     synth_preset,
     perm_csr,
     shard_rows,

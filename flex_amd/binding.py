@@ -20,6 +20,7 @@ _SO = os.path.join(_HERE, "lib", "libflex_spmm.so")
 FLEX_ORDER_NATURAL = 0
 FLEX_ORDER_RCM = 1
 FLEX_ORDER_CLUSTER = 2
+FLEX_ORDER_GORDER = 3
 
 
 class FlexError(RuntimeError):
@@ -60,7 +61,7 @@ class _SynthParams(C.Structure):  # flex_synth_params
 SYMBOLS = [
     "flex_plan_create", "flex_plan_create_mapped", "flex_plan_create_rows", "flex_spmm",
     "flex_plan_destroy", "flex_plan_get_info", "flex_gather_rows", "flex_csv_load",
-    "flex_host_csr_free", "flex_fill_dense_rand", "flex_order_rcm", "flex_order_cluster", "flex_perm_csr",
+    "flex_host_csr_free", "flex_fill_dense_rand", "flex_order_rcm", "flex_order_cluster", "flex_order_gorder", "flex_perm_csr",
     "flex_order_deg", "flex_shard_rows", "flex_synth_graph", "flex_synth_preset", "flex_strerror", "flex_last_hip_error",
     "flex_last_hip_error_string", "flex_abi_version",
 ]
@@ -109,6 +110,7 @@ def lib():
         L.flex_fill_dense_rand.argtypes = [vp, i64, i32]
         L.flex_order_rcm.argtypes = [C.POINTER(_Csr), vp]
         L.flex_order_cluster.argtypes = [C.POINTER(_Csr), vp]
+        L.flex_order_gorder.argtypes = [C.POINTER(_Csr), u32, vp]
         L.flex_order_deg.argtypes = [C.POINTER(_Csr), i32, vp]
         L.flex_synth_preset.argtypes = [C.c_char_p, i32, C.POINTER(_SynthParams)]
         L.flex_perm_csr.argtypes = [C.POINTER(_Csr), vp, vp, vp, vp, vp]
@@ -230,6 +232,13 @@ def synth_graph(name: str | None = None, *, scale: int = 1, n=None, nnz=None, al
     s = _HostCsr()
     _check(lib().flex_synth_graph(C.byref(p), C.byref(s)), f"flex_synth_graph({name or n})")
     return _take(s)
+
+
+def order_gorder(a: HostCsr, window: int = 3) -> np.ndarray:
+    rank = np.empty(max(a.m, 1), dtype=np.uint32)
+    v = a.view()
+    _check(lib().flex_order_gorder(C.byref(v), int(window), rank.ctypes.data), "flex_order_gorder")
+    return rank[: a.m]
 
 
 def order_deg(a: HostCsr, descending: bool = True) -> np.ndarray:

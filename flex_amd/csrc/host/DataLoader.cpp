@@ -167,6 +167,13 @@ DataLoaderDeg::DataLoaderDeg(const DataLoader &dl) : DataLoader(dl) {
     adopt_rank(dl, rank, "DEG");
 }
 
+DataLoaderGorder::DataLoaderGorder(const DataLoader &dl) : DataLoader(dl) {
+    std::vector<uint32_t> rank(n);
+    const flex_csr a = dl.csr_view();
+    FLEX_CHECK(flex_order_gorder(&a, /*window_sz=*/3, rank.data()));  // DataLoader.cu:808
+    adopt_rank(dl, rank, "GOR");
+}
+
 DataLoaderRabbit::DataLoaderRabbit(const DataLoader &dl) : DataLoader(dl) {
     std::vector<uint32_t> rank(n);
     const flex_csr a = dl.csr_view();

@@ -68,6 +68,10 @@ class DataLoaderDeg : public DataLoader {  // DataLoader.cu:657-721
    public:
     explicit DataLoaderDeg(const DataLoader &dl);
 };
+class DataLoaderGorder : public DataLoader {  // DataLoader.cu:789-857 (window 3)
+   public:
+    explicit DataLoaderGorder(const DataLoader &dl);
+};
 class DataLoaderRabbit : public DataLoader {  // DataLoader.cu:453-655 (community order; engine's own clustering)
    public:
     explicit DataLoaderRabbit(const DataLoader &dl);

@@ -149,6 +149,10 @@ void run(DataLoader &input_vo) {
         bench_one(rbt, FLEX_ORDER_NATURAL, "natural", input_vo, h_res.get(), perfRes, rows);
     }
     {
+        DataLoaderGorder gor(input_vo);
+        bench_one(gor, FLEX_ORDER_NATURAL, "natural", input_vo, h_res.get(), perfRes, rows);
+    }
+    {
         DataLoaderDeg deg(input_vo);
         bench_one(deg, FLEX_ORDER_NATURAL, "natural", input_vo, h_res.get(), perfRes, rows);
     }

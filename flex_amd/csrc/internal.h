@@ -55,6 +55,8 @@ int launch_gather_rows(float *dst, const float *src, const int32_t *idx, int64_t
 // host-side helpers shared by the ABI files
 int order_rcm_host(int64_t n, const uint32_t *rowPtr, const uint32_t *col, std::vector<uint32_t> &rank);
 int order_cluster_host(int64_t n, const uint32_t *rowPtr, const uint32_t *col, std::vector<uint32_t> &rank);
+int order_gorder_host(int64_t n, const uint32_t *rowPtr, const uint32_t *col, uint32_t window,
+                      std::vector<uint32_t> &rank);
 int validate_csr(const flex_csr *A);
 
 }  // namespace flex

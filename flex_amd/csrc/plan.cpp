@@ -96,7 +96,7 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     const int32_t m = r1 - r0;
     const int k = p->k;
     const unsigned order = flags & FLEX_ORDER_MASK;
-    if (order > FLEX_ORDER_CLUSTER) return FLEX_ERR_INVALID;
+    if (order > FLEX_ORDER_GORDER) return FLEX_ERR_INVALID;
     // graph orderings need the whole square matrix
     if (order != FLEX_ORDER_NATURAL && (A->m != A->n || r0 != 0 || r1 != A->m)) return FLEX_ERR_INVALID;
     p->order = order;
@@ -111,8 +111,9 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     std::vector<uint32_t> sched(m);
     if (order != FLEX_ORDER_NATURAL) {
         std::vector<uint32_t> rank;
-        int rc = order == FLEX_ORDER_RCM ? order_rcm_host(m, A->rowPtr, A->col, rank)
-                                         : order_cluster_host(m, A->rowPtr, A->col, rank);
+        int rc = order == FLEX_ORDER_RCM       ? order_rcm_host(m, A->rowPtr, A->col, rank)
+                 : order == FLEX_ORDER_CLUSTER ? order_cluster_host(m, A->rowPtr, A->col, rank)
+                                               : order_gorder_host(m, A->rowPtr, A->col, 3, rank);
         if (rc) return rc;
         for (int32_t r = 0; r < m; ++r) sched[rank[r]] = static_cast<uint32_t>(r);
     } else {
@@ -238,7 +239,7 @@ static int create_common(flex_plan **out, const flex_csr *hostA, int64_t row_beg
     *out = nullptr;
     if (k <= 0 || device < 0) return FLEX_ERR_INVALID;
     const unsigned order = flags & FLEX_ORDER_MASK;
-    if (order > FLEX_ORDER_CLUSTER) return FLEX_ERR_INVALID;
+    if (order > FLEX_ORDER_GORDER) return FLEX_ERR_INVALID;
     int rc = validate_csr(hostA);
     if (rc) return rc;
     if (hostA->m >= INT32_MAX) return FLEX_ERR_UNSUPPORTED;

@@ -60,6 +60,7 @@ typedef struct flex_plan flex_plan;
 #define FLEX_ORDER_CLUSTER 2u /* rows scheduled community by community (agglomerative modularity
                                  clustering, ≙ DataLoaderRabbit, DataLoader.cu:453-655); same
                                  no-permutation contract as FLEX_ORDER_RCM */
+#define FLEX_ORDER_GORDER 3u  /* rows scheduled in Gorder(window 3) order (≙ DataLoaderGorder, DataLoader.cu:789-857) */
 #define FLEX_ORDER_MASK 0xFu
 
 /* ≙ Mat::Mat + csr2_DiagTiling + alpha_transfer (mat.cu:7-31, 680-942, 268-293):
@@ -140,6 +141,11 @@ int flex_fill_dense_rand(float *hostB, int64_t n, int k);
 
 /* ≙ order_rcm(h) (order_rcm.cu:15-33): rank[old] = new. */
 int flex_order_rcm(const flex_csr *A, uint32_t *rank);
+
+/* ≙ complete_gorder(h, window) (order_gorder.cu:13-31; DataLoaderGorder uses window 3,
+ * DataLoader.cu:808): RCM, then Gorder with the lazy unit heap.  FLEX_ERR_UNSUPPORTED for a graph
+ * with an isolated vertex (the reference cannot order one either, unitheap.cu:35-38). */
+int flex_order_gorder(const flex_csr *A, uint32_t window, uint32_t *rank);
 
 /* ≙ order_deg(h, desc) (order_deg.cu:19-45): rank by in+out degree, ties by vertex id. */
 int flex_order_deg(const flex_csr *A, int descending, uint32_t *rank);

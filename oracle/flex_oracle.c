@@ -383,3 +383,288 @@ void oracle_perm_csr(int64_t n, const uint32_t *rowPtr, const uint32_t *col, con
     }
     free(perm);
 }
+
+/* ------------------------------------------------------------------ Gorder */
+/* complete_gorder(h, window): order_gorder.cu:13-31 = RCM, Badjlist in RCM ids
+ * (adjlist.cu:156-185), order_gorder (order_gorder.cu:35-84), move_window
+ * (order_gorder.cu:88-143) over the UnitHeap of unitheap.cu.  Restated literally,
+ * quirks included (ReConstruct links indices 0..heapsize-1, unitheap.cu:35-38). */
+
+typedef struct { int key; uint64_t prev, next; } uh_elem;
+typedef struct { uint64_t first, second; } uh_head;
+typedef struct {
+    int *update;
+    uh_elem *ll;
+    uh_head *hd;
+    size_t hd_size, n;
+    size_t heapsize;
+    uint64_t top, huge, none;
+    int infty;
+    int failed;
+} unitheap;
+
+static void uh_header_resize(unitheap *h, size_t sz) {
+    if (sz <= h->hd_size) return;
+    h->hd = (uh_head *)realloc(h->hd, sz * sizeof(uh_head));
+    for (size_t i = h->hd_size; i < sz; ++i) h->hd[i].first = h->hd[i].second = h->none;
+    h->hd_size = sz;
+}
+
+static void uh_init(unitheap *h, uint64_t size) { /* unitheap.cu:17-23 */
+    memset(h, 0, sizeof *h);
+    h->infty = 0x7fffffff / 2;
+    h->n = size;
+    h->none = size + 2;
+    h->huge = (uint64_t)sqrt((double)size);
+    h->ll = (uh_elem *)malloc(sizeof(uh_elem) * (size ? size : 1));
+    h->update = (int *)malloc(sizeof(int) * (size ? size : 1));
+    for (uint64_t i = 0; i < size; ++i) {
+        h->ll[i].key = h->infty;
+        h->ll[i].prev = h->ll[i].next = h->none;
+        h->update[i] = h->infty;
+    }
+}
+
+static void uh_free(unitheap *h) { free(h->ll); free(h->update); free(h->hd); }
+
+static unitheap *g_sort_heap;
+static int uh_cmp_desc(const void *a, const void *b) { /* unitheap.cu:40-42 */
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    int kx = g_sort_heap->ll[x].key, ky = g_sort_heap->ll[y].key;
+    if (kx != ky) return kx > ky ? -1 : 1;
+    return (x > y) - (x < y);
+}
+
+static void uh_reconstruct(unitheap *h) { /* unitheap.cu:34-70 */
+    size_t hs = h->heapsize;
+    uint64_t *g = (uint64_t *)malloc(sizeof(uint64_t) * (hs ? hs : 1));
+    for (size_t i = 0; i < hs; ++i) g[i] = i;
+    g_sort_heap = h;
+    qsort(g, hs, sizeof(uint64_t), uh_cmp_desc);
+    h->top = g[0];
+    int cur = h->ll[h->top].key;
+    uh_header_resize(h, (size_t)10 * cur + 1);
+    h->hd[cur].first = h->top;
+    for (size_t i = 0; i < hs; ++i) {
+        uint64_t v = g[i];
+        h->ll[v].prev = i > 0 ? g[i - 1] : h->none;
+        h->ll[v].next = i + 1 < hs ? g[i + 1] : h->none;
+        int key = h->ll[v].key;
+        if (key != cur) {
+            h->hd[cur].second = g[i - 1];
+            h->hd[key].first = g[i];
+            cur = key;
+        }
+    }
+    h->hd[cur].second = g[hs - 1];
+    free(g);
+}
+
+static void uh_erase_key(unitheap *h, uint64_t idx, uint64_t next, uint64_t prev) { /* unitheap.cu:76-84 */
+    int key = h->ll[idx].key;
+    if (h->hd[key].first == h->hd[key].second) h->hd[key].first = h->hd[key].second = h->none;
+    else if (idx == h->hd[key].first) h->hd[key].first = next;
+    else if (idx == h->hd[key].second) h->hd[key].second = prev;
+}
+
+static void uh_delete(unitheap *h, uint64_t idx) { /* unitheap.cu:161-178 */
+    h->update[idx] = h->infty;
+    uint64_t prev = h->ll[idx].prev, next = h->ll[idx].next;
+    if (prev != h->none) h->ll[prev].next = next;
+    if (next != h->none) h->ll[next].prev = prev;
+    uh_erase_key(h, idx, next, prev);
+    if (h->top == idx) h->top = next;
+    h->ll[idx].prev = h->ll[idx].next = h->none;
+    h->heapsize--;
+}
+
+static void uh_decrease_top(unitheap *h) { /* unitheap.cu:107-158 */
+    const uint64_t top = h->top, next = h->ll[top].next;
+    if (next == h->none) return;
+    const int key = h->ll[top].key;
+    const int leftover = h->update[top] / 2;
+    const int new_key = key + h->update[top] - leftover;
+    if (-h->update[top] > key) { h->failed = 1; return; }
+    if (new_key >= h->ll[next].key) return;
+    h->update[top] = leftover;
+    uint64_t level_tail = h->hd[key].second;
+    uint64_t next_level = h->ll[level_tail].next;
+    while (next_level != h->none && h->ll[next_level].key >= new_key) {
+        level_tail = h->hd[h->ll[next_level].key].second;
+        next_level = h->ll[level_tail].next;
+    }
+    h->ll[next].prev = h->none;
+    h->ll[top].prev = level_tail;
+    h->ll[top].next = next_level;
+    h->ll[level_tail].next = top;
+    if (next_level != h->none) h->ll[next_level].prev = top;
+    uh_erase_key(h, top, next, h->none);
+    if (new_key < 0) { h->failed = 1; return; }
+    h->ll[top].key = new_key;
+    h->hd[new_key].second = top;
+    if (h->hd[new_key].first == h->none) h->hd[new_key].first = top;
+    h->top = next;
+}
+
+static uint64_t uh_extract_max(unitheap *h) { /* unitheap.cu:90-104 */
+    uint64_t tmptop;
+    do {
+        tmptop = h->top;
+        if (h->update[h->top] < 0) uh_decrease_top(h);
+        if (h->failed) return h->none;
+    } while (h->top != tmptop);
+    uh_delete(h, h->top == tmptop ? tmptop : tmptop); /* DeleteElement(top): top == tmptop here */
+    return tmptop;
+}
+
+static void uh_increment_key(unitheap *h, uint64_t idx) { /* unitheap.cu:195-224 */
+    const uint64_t level_head = h->hd[h->ll[idx].key].first;
+    const uint64_t prev = h->ll[idx].prev, next = h->ll[idx].next;
+    if (level_head != idx) {
+        h->ll[prev].next = next;
+        if (next != h->none) h->ll[next].prev = prev;
+        uint64_t prev_level = h->ll[level_head].prev;
+        h->ll[idx].prev = prev_level;
+        h->ll[idx].next = level_head;
+        h->ll[level_head].prev = idx;
+        if (prev_level != h->none) h->ll[prev_level].next = idx;
+    }
+    uh_erase_key(h, idx, next, prev);
+    int key = ++h->ll[idx].key;
+    h->hd[key].second = idx;
+    if (h->hd[key].first == h->none) {
+        h->hd[key].first = idx;
+        if (key > h->ll[h->top].key) h->top = idx;
+    }
+    if ((size_t)key + 4 >= h->hd_size) uh_header_resize(h, (size_t)(h->hd_size * 1.5));
+}
+
+static void uh_lazy_increment(unitheap *h, uint64_t idx, int up) { /* unitheap.cu:185-193 */
+    if (h->update[idx] == h->infty) return;
+    if (h->update[idx] == 0 && up > 0) uh_increment_key(h, idx);
+    else {
+        h->update[idx] += up;
+        if (-h->update[idx] > h->ll[idx].key) h->failed = 1;
+    }
+}
+
+typedef struct { uint64_t n; uint64_t *cd; uint64_t *adj; } badj; /* out lists [0,n), in lists [n,2n) */
+
+static void gorder_move_window(const badj *g, unitheap *h, uint64_t new_node, uint64_t old_node,
+                               uint64_t *tmp_old, uint64_t *tmp_new) { /* order_gorder.cu:88-143 */
+    const uint64_t n = g->n;
+#define OUT_DEG(u) (g->cd[(u) + 1] - g->cd[u])
+    const uint64_t *old_p = g->adj + g->cd[old_node + n], *old_e = g->adj + g->cd[old_node + 1 + n];
+    const uint64_t *new_p = g->adj + g->cd[new_node + n], *new_e = g->adj + g->cd[new_node + 1 + n];
+    if (old_node == new_node) old_p = old_e;
+    else if (OUT_DEG(old_node) <= h->huge)
+        for (uint64_t a = g->cd[old_node]; a < g->cd[old_node + 1]; ++a) uh_lazy_increment(h, g->adj[a], -1);
+    size_t n_old = 0, n_new = 0;
+    for (;;) {
+        int factor = -1;
+        if (old_p >= old_e) {
+            if (new_p >= new_e) break;
+            factor = 1;
+        } else if (new_p < new_e) {
+            if (*new_p == *old_p) { old_p++; new_p++; continue; }
+            if (*new_p < *old_p) factor = 1;
+        }
+        if (factor == -1) {
+            if (OUT_DEG(*old_p) <= h->huge) tmp_old[n_old++] = *old_p;
+            old_p++;
+        } else {
+            if (OUT_DEG(*new_p) <= h->huge) tmp_new[n_new++] = *new_p;
+            new_p++;
+        }
+    }
+    for (size_t i = 0; i < n_old; ++i) {
+        const uint64_t parent = tmp_old[i];
+        uh_lazy_increment(h, parent, -1);
+        for (uint64_t a = g->cd[parent]; a < g->cd[parent + 1]; ++a)
+            if (g->adj[a] != old_node) uh_lazy_increment(h, g->adj[a], -1);
+    }
+    if (OUT_DEG(new_node) <= h->huge)
+        for (uint64_t a = g->cd[new_node]; a < g->cd[new_node + 1]; ++a) uh_lazy_increment(h, g->adj[a], +1);
+    for (size_t i = 0; i < n_new; ++i) {
+        const uint64_t parent = tmp_new[i];
+        uh_lazy_increment(h, parent, +1);
+        for (uint64_t a = g->cd[parent]; a < g->cd[parent + 1]; ++a)
+            if (g->adj[a] != new_node) uh_lazy_increment(h, g->adj[a], +1);
+    }
+#undef OUT_DEG
+}
+
+int oracle_order_gorder(int64_t n, const uint32_t *rowPtr, const uint32_t *col, uint64_t window, uint64_t *rank) {
+    if (n == 0) return 0;
+    const uint64_t e = rowPtr[n];
+    uint64_t *rank_rcm = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n);
+    int rc = oracle_order_rcm(n, rowPtr, col, rank_rcm);
+    if (rc) { free(rank_rcm); return rc; }
+    /* Badjlist g(h, rank_rcm): adjlist.cu:156-185, neighbours sorted (adjlist.cu:62-73) */
+    badj g;
+    g.n = (uint64_t)n;
+    g.cd = (uint64_t *)calloc((size_t)2 * n + 1, sizeof(uint64_t));
+    g.adj = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(e ? 2 * e : 1));
+    uint64_t *fill = (uint64_t *)calloc((size_t)2 * n + 1, sizeof(uint64_t));
+    for (int64_t i = 0; i < n; ++i)
+        for (uint32_t j = rowPtr[i]; j < rowPtr[i + 1]; ++j) {
+            g.cd[rank_rcm[i] + 1]++;
+            g.cd[rank_rcm[col[j]] + n + 1]++;
+        }
+    for (int64_t u = 0; u < 2 * n; ++u) g.cd[u + 1] += g.cd[u];
+    for (int64_t i = 0; i < n; ++i)
+        for (uint32_t j = rowPtr[i]; j < rowPtr[i + 1]; ++j) {
+            const uint64_t u = rank_rcm[i], v = rank_rcm[col[j]];
+            g.adj[g.cd[u] + fill[u]++] = v;
+            g.adj[g.cd[v + n] + fill[v + n]++] = u;
+        }
+    for (int64_t u = 0; u < 2 * n; ++u) qsort(g.adj + g.cd[u], (size_t)(g.cd[u + 1] - g.cd[u]), sizeof(uint64_t), cmp_u64);
+    /* order_gorder: order_gorder.cu:35-84 */
+    unitheap h;
+    uh_init(&h, (uint64_t)n);
+    uint64_t *order = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n);
+    uint64_t *isolates = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n);
+    uint64_t *tmp_old = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n + 1));
+    uint64_t *tmp_new = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(n + 1));
+    size_t n_order = 0, n_iso = 0;
+    for (int64_t u = 0; u < n; ++u) {
+        const uint64_t dout = g.cd[u + 1] - g.cd[u], din = g.cd[u + 1 + n] - g.cd[u + n];
+        if (dout + din == 0) isolates[n_iso++] = (uint64_t)u;
+        else { /* InsertElement, unitheap.cu:24-29 */
+            h.ll[u].key = (int)din;
+            h.update[u] = -(int)din;
+            h.heapsize++;
+        }
+    }
+    rc = 0;
+    /* With an isolated vertex the reference's ReConstruct links indices 0..heapsize-1 instead of the
+     * inserted ids (unitheap.cu:35-38), picks up a key of INT_MAX/2 and sizes Header to 10x that:
+     * it cannot complete.  Reported as a domain error instead of reproducing the crash. */
+    if (n_iso > 0) rc = -EDOM;
+    if (h.heapsize > 0 && !rc) {
+        uh_reconstruct(&h);
+        const uint64_t hub = h.top;
+        order[n_order++] = hub;
+        uh_delete(&h, hub);
+        gorder_move_window(&g, &h, hub, hub, tmp_old, tmp_new);
+        while (h.heapsize > 0 && !h.failed) {
+            const uint64_t nn = uh_extract_max(&h);
+            if (h.failed || nn >= (uint64_t)n) { rc = -EDOM; break; }
+            order[n_order++] = nn;
+            uint64_t old_node = nn;
+            if (n_order > window) old_node = order[n_order - window - 1];
+            gorder_move_window(&g, &h, nn, old_node, tmp_old, tmp_new);
+        }
+        if (h.failed) rc = -EDOM;
+    }
+    for (size_t i = 0; i < n_iso && n_order < (size_t)n; ++i) order[n_order++] = isolates[i];
+    if (!rc && n_order != (size_t)n) rc = -EDOM;
+    if (!rc) {
+        uint64_t *rank_g = fill; /* reuse: rank_from_order */
+        for (int64_t i = 0; i < n; ++i) rank_g[order[i]] = (uint64_t)i;
+        for (int64_t u = 0; u < n; ++u) rank[u] = rank_g[rank_rcm[u]]; /* order_gorder.cu:26-29 */
+    }
+    uh_free(&h);
+    free(order); free(isolates); free(tmp_old); free(tmp_new); free(fill); free(g.cd); free(g.adj); free(rank_rcm);
+    return rc;
+}

@@ -71,7 +71,12 @@ int64_t oracle_rescheck(const float *gold, const float *res, const uint32_t *ori
  * rank[old] = new. */
 int oracle_order_rcm(int64_t n, const uint32_t *rowPtr, const uint32_t *col, uint64_t *rank);
 
-/* DataLoaderRcm body, DataLoader.cu:741-779: given
+/* complete_gorder(h, window), order_gorder.cu:13-31: RCM first, then Gorder over the RCM-relabelled
+ * graph with the lazy unit heap of unitheap.cu; rank[old] = new.  DataLoaderGorder uses window 3
+ * (DataLoader.cu:808). */
+int oracle_order_gorder(int64_t n, const uint32_t *rowPtr, const uint32_t *col, uint64_t window, uint64_t *rank);
+
+/* DataLoaderRcm / DataLoaderGorder body, DataLoader.cu:741-779 / 815-850: given
  * rank[old]=new, build vo_mp[new]=old and the permuted CSR with columns mapped and
  * sorted ascending per row. Output arrays are caller-allocated (same sizes). */
 void oracle_perm_csr(int64_t n, const uint32_t *rowPtr, const uint32_t *col, const float *vals,

@@ -55,6 +55,9 @@ def main():
     out["pubmed_rcm_rowPtr_head"] = rp2[:65].copy()
     out["pubmed_rcm_col_head"] = c2[:256].copy()
     out["pubmed_rcm_bandwidth"] = np.int64(bandwidth(rp2, c2))
+    # Gorder(window 3) over RCM (DataLoaderGorder, DataLoader.cu:789-857).  The reference records no
+    # figure for it, so this vector is a regression pin of the oracle's literal restatement only.
+    out["pubmed_gorder_w3_rank"] = oracle.order_gorder(p.rowPtr, p.col, 3).astype(np.int32)
     np.savez_compressed(os.path.join(HERE, "golden.npz"), **out)
     print("wrote", os.path.join(HERE, "golden.npz"), {k: np.shape(v) for k, v in out.items()})
 

@@ -149,3 +149,33 @@ def test_no_gpu_fails_loudly_never_falls_back():
     good = flex_amd.HostCsr([0, 1], [0], [1.0])
     with pytest.raises(flex_amd.FlexError, match="HIP runtime call failed"):
         flex_amd.Plan(good, 32)
+
+
+def test_gorder_equals_oracle(golden):
+    for name in ("pubmed.csv", "a_mat.csv"):
+        a = flex_amd.csv_load(os.path.join(GOLDEN, name))
+        for w in (1, 3, 5):
+            assert np.array_equal(flex_amd.order_gorder(a, w).astype(np.uint64), oracle.order_gorder(a.rowPtr, a.col, w))
+    a = flex_amd.csv_load(os.path.join(GOLDEN, "pubmed.csv"))
+    assert np.array_equal(flex_amd.order_gorder(a, 3).astype(np.int32), golden["pubmed_gorder_w3_rank"])
+    for seed in (1, 2):
+        g = flex_amd.synth_graph(n=3000, nnz=3000 + 2 * 20000, community=50, p_in=0.5, p_near=0.2, seed=seed)
+        assert np.array_equal(flex_amd.order_gorder(g).astype(np.uint64), oracle.order_gorder(g.rowPtr, g.col, 3))
+    iso = flex_amd.HostCsr([0, 1, 1, 2], [2, 0], [1.0, 1.0])
+    with pytest.raises(flex_amd.FlexError, match="not supported"):
+        flex_amd.order_gorder(iso)
+
+
+def test_cluster_and_deg_orders_are_permutations_with_locality():
+    g = flex_amd.synth_graph(n=20000, nnz=20000 + 2 * 100000, community=100, p_in=0.6, p_near=0.2, seed=4)
+    rows = np.repeat(np.arange(g.m), np.diff(g.rowPtr.astype(np.int64)))
+
+    def near(rank, w=256):
+        return float(np.mean(np.abs(rank[rows].astype(np.int64) - rank[g.col].astype(np.int64)) < w))
+    clu, deg = flex_amd.order_cluster(g), flex_amd.order_deg(g)
+    for r in (clu, deg):
+        assert sorted(r.tolist()) == list(range(g.n))
+    # the community order must recover most of the planted locality that the shuffle destroyed
+    assert near(clu) > 3 * near(np.arange(g.n)) and near(clu) > 0.3
+    d = np.diff(g.rowPtr.astype(np.int64)) * 2 - 1  # in+out degree of a symmetric graph with self loops
+    assert np.all(np.diff(d[np.argsort(deg)]) <= 0)  # order_deg(desc): degrees descend along the new order

@@ -44,7 +44,7 @@ def test_a_mat_golden(golden):
 
 
 @pytest.mark.parametrize("k", [32, 128])
-@pytest.mark.parametrize("order", [FLEX_ORDER_NATURAL, FLEX_ORDER_RCM])
+@pytest.mark.parametrize("order", [FLEX_ORDER_NATURAL, FLEX_ORDER_RCM, flex_amd.FLEX_ORDER_CLUSTER, flex_amd.FLEX_ORDER_GORDER])
 def test_pubmed_vs_oracle_and_golden(golden, k, order):
     a = flex_amd.csv_load(os.path.join(GOLDEN, "pubmed.csv"))
     B = oracle.gen_B(a.n, k)  # the reference's rand() B (DataLoader.cu:198-209)
@@ -243,7 +243,7 @@ def test_cxx_host_mirror_cli_pubmed_and_amat():
         assert out.returncode == 0, out.stdout + out.stderr
         rows = [json.loads(line) for line in out.stdout.splitlines() if line.startswith("{")]
         assert {(r["ord"], r["schedule"]) for r in rows} >= {("OVO", "natural"), ("OVO", "cluster"), ("RCM", "natural"),
-                                                             ("RBT", "natural"), ("DEG", "natural")}
+                                                             ("RBT", "natural"), ("DEG", "natural"), ("GOR", "natural")}
         assert all(r["errs"] == 0 for r in rows)
     assert "hipSPARSE setup" in out.stdout
 

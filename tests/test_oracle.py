@@ -178,3 +178,25 @@ def test_amazon_branch_uses_rand(tmp_path):
     assert np.allclose(a.vals, [0.680375, -0.211234], atol=5e-7) and a.c == 107
     B = oracle.gen_B(2, 1, reset_rand=False)      # continues the same rand() stream
     assert np.allclose(B.ravel(), [0.566198, 0.59688], atol=5e-7)
+
+
+def test_gorder_is_a_permutation_and_improves_its_objective(pubmed, golden):
+    # Gorder maximises, over a sliding window, the number of neighbour/sibling pairs placed close together
+    r = oracle.order_gorder(pubmed.rowPtr, pubmed.col, 3)
+    assert sorted(r.tolist()) == list(range(pubmed.n))
+    assert np.array_equal(r.astype(np.int32), golden["pubmed_gorder_w3_rank"])
+    rows = np.repeat(np.arange(pubmed.n), np.diff(pubmed.rowPtr.astype(np.int64)))
+
+    def close_pairs(rank, w=3):
+        d = np.abs(rank[rows].astype(np.int64) - rank[pubmed.col].astype(np.int64))
+        return int(np.sum((d > 0) & (d <= w)))
+    rcm = oracle.order_rcm(pubmed.rowPtr, pubmed.col)
+    assert close_pairs(r) > 5 * close_pairs(rcm) > close_pairs(np.arange(pubmed.n))
+
+
+def test_gorder_refuses_isolated_vertices():
+    # the reference cannot complete on such a graph (unitheap.cu:35-38); the oracle reports it
+    rp = np.array([0, 1, 1, 2], dtype=np.uint32)   # vertex 1 has no edge at all
+    col = np.array([2, 0], dtype=np.uint32)
+    with pytest.raises(RuntimeError):
+        oracle.order_gorder(rp, col, 3)
