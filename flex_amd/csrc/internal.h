@@ -8,6 +8,11 @@
 
 namespace flex {
 
+// One split row: C[row,:] = sum of partial[first .. first+count) in that order.
+struct SplitRow {
+    uint32_t row, first, count;
+};
+
 // What the SpMM kernels read.  Passed by value as a kernel argument (the reference
 // copies a ~270-byte Mat_POD into __constant__ memory instead: mat.cuh:18-65, mat.cu:32-41).
 struct PlanView {
@@ -16,6 +21,11 @@ struct PlanView {
     const uint32_t *t_dst;   // [n_tasks]   C row written by the task; MSB set -> partial slot id
     const uint4 *chunk;      // [n_chunks] {first task, #tasks (<= 63), first record, end record}; one wave per chunk
     float *partial;          // [n_partials][k] partial sums of split rows
+    const uint32_t *piece_row;  // [n_partials] index into `split` of the row a piece belongs to
+    const SplitRow *split;   // [n_split] {C row, first partial, #pieces}
+    uint32_t *split_cnt;     // [n_split][k-tiles] arrival counters, zero between launches
+    uint32_t partial_bytes;  // size of `partial` (buffer-descriptor range)
+    uint32_t fused_fixup;    // 1: the last piece to finish sums the row inside the launch; 0: spmm_fixup_kernel does
     uint32_t n_chunks;
     int32_t k;
     uint32_t xcd_remap;      // 1: remap workgroup ids so each XCD walks one contiguous slice of the schedule
@@ -23,11 +33,6 @@ struct PlanView {
     uint64_t *trace;         // diagnostic builds (-DFLEX_TRACE) only: 6 words per wave; nullptr otherwise
 };
 
-
-// One split row: C[row,:] = sum of partial[first .. first+count) in that order.
-struct SplitRow {
-    uint32_t row, first, count;
-};
 
 constexpr uint32_t kPartialFlag = 0x80000000u;
 constexpr int kWavesPerBlock = 4;  // 256-thread workgroups

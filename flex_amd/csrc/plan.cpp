@@ -63,6 +63,9 @@ struct flex_plan {
     uint4 *d_chunk = nullptr;
     float *d_partial = nullptr;
     SplitRow *d_split = nullptr;
+    uint32_t *d_piece_row = nullptr, *d_split_cnt = nullptr;
+    uint32_t partial_bytes = 0;
+    bool fused_fixup = false;
     uint32_t n_tasks = 0, n_chunks = 0, n_split = 0, n_partials = 0;
     int64_t device_bytes = 0;
     double plan_ms = 0;
@@ -87,6 +90,8 @@ void free_plan_device(flex_plan *p) {
     (void)hipFree(p->d_chunk);
     (void)hipFree(p->d_partial);
     (void)hipFree(p->d_split);
+    (void)hipFree(p->d_piece_row);
+    (void)hipFree(p->d_split_cnt);
 }
 
 // Rows [r0,r1) of A.  col_map: B row read by column c (NULL = c).  dst_map: C row
@@ -223,7 +228,17 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     p->n_chunks = static_cast<uint32_t>(chunk.size());
     if ((rc = upload(&p->d_chunk, chunk, &p->device_bytes))) return rc;
     if ((rc = upload(&p->d_split, split, &p->device_bytes))) return rc;
+    std::vector<uint32_t> piece_row(n_partials);
+    for (uint32_t si = 0; si < split.size(); ++si)
+        for (uint32_t j = 0; j < split[si].count; ++j) piece_row[split[si].first + j] = si;
+    if ((rc = upload(&p->d_piece_row, piece_row, &p->device_bytes))) return rc;
+    const size_t ktiles = (static_cast<size_t>(k) + 4 * G - 1) / (4 * G);
+    std::vector<uint32_t> zeros(std::max<size_t>(1, split.size() * ktiles), 0u);
+    if ((rc = upload(&p->d_split_cnt, zeros, &p->device_bytes))) return rc;
     const size_t pbytes = std::max<size_t>(1, static_cast<size_t>(n_partials) * k) * sizeof(float);
+    // the in-launch reduction addresses `partial` through a buffer descriptor (32-bit range)
+    p->fused_fixup = pbytes < (size_t(1) << 32) && env_long("FLEX_FUSED_FIXUP", 1) == 1;
+    p->partial_bytes = static_cast<uint32_t>(std::min<size_t>(pbytes, 0xFFFFFFFFu));
     FLEX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_partial), pbytes));
     p->device_bytes += static_cast<int64_t>(pbytes);
     return FLEX_OK;
@@ -300,13 +315,15 @@ int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream) {
     int cur = -1;
     FLEX_HIP_TRY(hipGetDevice(&cur));
     if (cur != p->device) FLEX_HIP_TRY(hipSetDevice(p->device));
-    PlanView v{p->d_rec, p->d_t_beg, p->d_t_dst, p->d_chunk, p->d_partial, p->n_chunks, p->k,
-               p->xcd_remap ? 1u : 0u, p->lds_extra, p->trace};
     const bool vec4 = (p->k % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(dB) | reinterpret_cast<uintptr_t>(dC)) % 16 == 0);
+    const bool fused = vec4 && p->fused_fixup;  // the generic kernel always leaves the sum to spmm_fixup_kernel
+    PlanView v{p->d_rec, p->d_t_beg, p->d_t_dst, p->d_chunk, p->d_partial, p->d_piece_row, p->d_split, p->d_split_cnt,
+               p->partial_bytes, fused ? 1u : 0u, p->n_chunks, p->k,
+               p->xcd_remap ? 1u : 0u, p->lds_extra, p->trace};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc = launch_spmm(v, p->lanes_per_nz, p->off32, vec4, dB, dC, s);
-    if (rc == FLEX_OK) rc = launch_fixup(p->d_partial, p->d_split, p->n_split, p->k, dC, s);
+    if (rc == FLEX_OK && !fused) rc = launch_fixup(p->d_partial, p->d_split, p->n_split, p->k, dC, s);
     if (cur != p->device) (void)hipSetDevice(cur);
     return rc;
 }

@@ -55,6 +55,7 @@ __device__ __forceinline__ void fma4(float4 &acc, float v, const float4 &b) {
 }
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
 // x[l] + x[l ^ 32] in every lane.  v_permlane32_swap exchanges the upper half of its first
 // operand with the lower half of its second; fed (x, x) it yields {lo,lo} and {hi,hi}.
@@ -115,6 +116,8 @@ __device__ __forceinline__ void process_chunk(const PlanView &p, uint32_t c, uin
     uint32_t ti = 0;                                          // current task
     uint32_t row_end = __builtin_amdgcn_readlane(my_beg, 1);  // where it ends in the record stream
     float4 acc = {0.f, 0.f, 0.f, 0.f};
+    float4 piece_sum = {0.f, 0.f, 0.f, 0.f};
+    uint32_t piece_dst = 0;  // kPartialFlag | slot once this chunk turned out to be a piece of a split row
 
     // write out every task that ends at stream position `pos` (several when rows are empty)
     auto drain = [&](uint32_t pos) {
@@ -134,17 +137,16 @@ __device__ __forceinline__ void process_chunk(const PlanView &p, uint32_t c, uin
                 r.w = xor32_sum(r.w);
             }
             const uint32_t dst = __builtin_amdgcn_readlane(my_dst, ti);
-            if (slot == 0 && col_ok) {
-                if (dst & kPartialFlag) {
-                    *reinterpret_cast<float4 *>(p.partial + static_cast<uint64_t>(dst & ~kPartialFlag) * k + c0) = r;
-                } else {
-#ifdef FLEX_PLAIN_STORE
-                    *reinterpret_cast<float4 *>(C + static_cast<uint64_t>(dst) * k + c0) = r;
-#else
+            if (!(dst & kPartialFlag)) {
+                if (slot == 0 && col_ok) {
                     const v4f val = {r.x, r.y, r.z, r.w};
                     __builtin_nontemporal_store(val, reinterpret_cast<v4f *>(C + static_cast<uint64_t>(dst) * k + c0));
-#endif
                 }
+            } else {
+                // a piece of a split row is a chunk of its own (planner invariant): remember its sum and
+                // combine after the loops, where the gather registers are dead (keeps the hot loop lean)
+                piece_sum = r;
+                piece_dst = dst;
             }
             acc = {0.f, 0.f, 0.f, 0.f};
             ++ti;
@@ -179,6 +181,58 @@ __device__ __forceinline__ void process_chunk(const PlanView &p, uint32_t c, uin
                 }
             }
             FLEX_STAMP(3);  // fma + row flushes
+        }
+    }
+    if (piece_dst & kPartialFlag) {
+        const float4 r = piece_sum;
+        const uint32_t ps = piece_dst & ~kPartialFlag;
+        if (!p.fused_fixup) {  // partial sums are combined by spmm_fixup_kernel after this launch
+            if (slot == 0 && col_ok) *reinterpret_cast<float4 *>(p.partial + static_cast<uint64_t>(ps) * k + c0) = r;
+        } else {
+            // Combined inside this launch by whichever piece finishes LAST (cdna guide G16, counter form
+            // with write-through payload): (1) the partial sum is stored write-through (sc1), so it is at
+            // device scope when the store completes; (2) this wave drains its stores; (3) one lane bumps
+            // the row's arrival counter (agent-scope atomic); (4) the wave whose add returns count-1 knows
+            // every piece is visible, reads all of them with sc1 loads (never through its CU's L1) and
+            // adds them in PIECE order -- the sum is reproducible although the reducer is not -- and
+            // re-arms the counter for the next launch.
+            const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, p.partial_bytes, 0x00020000);
+            if (slot == 0 && col_ok) {
+                const v4u pv = {__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z), __float_as_uint(r.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(pv, prsrc, (ps * k + c0) * 4u, 0, 16 /* sc1 */);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t sidx = p.piece_row[ps];
+            const SplitRow sr = p.split[sidx];
+            uint32_t *cnt = p.split_cnt + static_cast<uint64_t>(sidx) * gridDim.y + blockIdx.y;
+            uint32_t arrived = 0;
+            if (lane == 0) arrived = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            arrived = __builtin_amdgcn_readfirstlane(arrived);
+            if (arrived == sr.count - 1) {
+                float4 s4 = {0.f, 0.f, 0.f, 0.f};
+                if (slot == 0 && col_ok) {
+                    for (uint32_t j = 0; j < sr.count; j += 8) {
+                        v4u v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const uint32_t jj = min(j + u, sr.count - 1);
+                            v[u] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, ((sr.first + jj) * k + c0) * 4u, 0, 16 /* sc1 */);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            if (j + u < sr.count) {
+                                s4.x += __uint_as_float(v[u].x);
+                                s4.y += __uint_as_float(v[u].y);
+                                s4.z += __uint_as_float(v[u].z);
+                                s4.w += __uint_as_float(v[u].w);
+                            }
+                        }
+                    }
+                    const v4f val = {s4.x, s4.y, s4.z, s4.w};
+                    __builtin_nontemporal_store(val, reinterpret_cast<v4f *>(C + static_cast<uint64_t>(sr.row) * k + c0));
+                }
+                if (lane == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }

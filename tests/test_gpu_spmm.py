@@ -270,3 +270,40 @@ def test_vendor_baseline_matches_oracle():
     torch.cuda.synchronize()
     V.flex_vendor_spmm_destroy(h)
     assert_matches_oracle(a, B, Cd.cpu().numpy())
+
+
+def test_in_launch_split_row_reduction_is_stable_under_repetition():
+    """Split rows are summed inside the launch by the last piece to arrive (write-through partial sums,
+    agent-scope arrival counter, sc1 re-reads).  A visibility bug would show as a rare wrong row:
+    hammer a plan that is mostly split rows and require every launch to be bit-identical and correct."""
+    a = random_csr(6000, 6000, 8, seed=91, long_rows={r: 700 + 13 * (r % 97) for r in range(0, 6000, 3)}, empty_frac=0.05)
+    k = 128
+    Bn = random_B(a.n, k, 92)
+    B = dev(Bn)
+    p = Plan(a, k)
+    info = p.info()
+    assert info["n_split_rows"] >= 1900 and info["n_partials"] > 10000
+    ref = p(B).clone()
+    torch.cuda.synchronize()
+    assert_matches_oracle(a, Bn, ref.cpu().numpy(), nthreads=8)
+    C = torch.empty_like(ref)
+    filler = torch.empty(64 << 20, device="cuda")  # unrelated traffic between launches (uneven load)
+    for it in range(300):
+        C.fill_(float("nan"))
+        if it % 3 == 0:
+            filler.add_(1.0)
+        p(B, out=C)
+        if it % 25 == 24 or it < 4:
+            torch.cuda.synchronize()
+            assert torch.equal(C, ref), f"launch {it}: result changed"
+    torch.cuda.synchronize()
+    assert torch.equal(C, ref)
+    # several plans alive at once, launched back to back on one stream
+    p2 = Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER)
+    r2 = p2(B).clone()
+    for _ in range(50):
+        p(B, out=C)
+        c2 = p2(B)
+    torch.cuda.synchronize()
+    assert torch.equal(C, ref) and torch.equal(c2, r2)
+    assert oracle.rescheck(ref.cpu().numpy(), r2.cpu().numpy(), a.rowPtr)[0] == 0
