@@ -23,6 +23,7 @@ from .binding import (  # noqa: F401
     order_rcm,
     order_cluster,
     order_deg,
+    order_dfs,
     order_gorder,
     synth_preset,
     perm_csr,

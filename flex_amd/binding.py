@@ -54,7 +54,7 @@ class _SynthParams(C.Structure):  # flex_synth_params
     _fields_ = [("n", C.c_int64), ("nnz", C.c_int64), ("alpha", C.c_double),
                 ("community", C.c_int64), ("p_in", C.c_double), ("p_near", C.c_double),
                 ("near_window", C.c_int32), ("shuffle", C.c_int32), ("gcn_norm", C.c_int32),
-                ("seed", C.c_uint64)]
+                ("directed", C.c_int32), ("seed", C.c_uint64)]
 
 
 # every symbol include/flex_spmm.h declares (tests/test_abi.py checks the header against this)
@@ -62,7 +62,7 @@ SYMBOLS = [
     "flex_plan_create", "flex_plan_create_mapped", "flex_plan_create_rows", "flex_spmm",
     "flex_plan_destroy", "flex_plan_get_info", "flex_gather_rows", "flex_csv_load",
     "flex_host_csr_free", "flex_fill_dense_rand", "flex_order_rcm", "flex_order_cluster", "flex_order_gorder", "flex_perm_csr",
-    "flex_order_deg", "flex_shard_rows", "flex_synth_graph", "flex_synth_preset", "flex_strerror", "flex_last_hip_error",
+    "flex_order_deg", "flex_order_dfs", "flex_shard_rows", "flex_synth_graph", "flex_synth_preset", "flex_strerror", "flex_last_hip_error",
     "flex_last_hip_error_string", "flex_abi_version",
 ]
 
@@ -111,6 +111,7 @@ def lib():
         L.flex_order_rcm.argtypes = [C.POINTER(_Csr), vp]
         L.flex_order_cluster.argtypes = [C.POINTER(_Csr), vp]
         L.flex_order_gorder.argtypes = [C.POINTER(_Csr), u32, vp]
+        L.flex_order_dfs.argtypes = [C.POINTER(_Csr), vp]
         L.flex_order_deg.argtypes = [C.POINTER(_Csr), i32, vp]
         L.flex_synth_preset.argtypes = [C.c_char_p, i32, C.POINTER(_SynthParams)]
         L.flex_perm_csr.argtypes = [C.POINTER(_Csr), vp, vp, vp, vp, vp]
@@ -222,13 +223,13 @@ def synth_preset(name: str, scale: int = 1) -> _SynthParams:
 
 
 def synth_graph(name: str | None = None, *, scale: int = 1, n=None, nnz=None, alpha=2.1, community=0, p_in=0.0,
-                p_near=0.0, near_window=8, shuffle=True, gcn_norm=True, seed=0xF1E0) -> HostCsr:
+                p_near=0.0, near_window=8, shuffle=True, gcn_norm=True, directed=False, seed=0xF1E0) -> HostCsr:
     if name is not None:
         p = synth_preset(name, scale)
         p.shuffle = int(bool(shuffle))
     else:
         p = _SynthParams(int(n), int(nnz), float(alpha), int(community), float(p_in), float(p_near),
-                         int(near_window), int(bool(shuffle)), int(bool(gcn_norm)), int(seed))
+                         int(near_window), int(bool(shuffle)), int(bool(gcn_norm)), int(bool(directed)), int(seed))
     s = _HostCsr()
     _check(lib().flex_synth_graph(C.byref(p), C.byref(s)), f"flex_synth_graph({name or n})")
     return _take(s)
@@ -238,6 +239,13 @@ def order_gorder(a: HostCsr, window: int = 3) -> np.ndarray:
     rank = np.empty(max(a.m, 1), dtype=np.uint32)
     v = a.view()
     _check(lib().flex_order_gorder(C.byref(v), int(window), rank.ctypes.data), "flex_order_gorder")
+    return rank[: a.m]
+
+
+def order_dfs(a: HostCsr) -> np.ndarray:
+    rank = np.empty(max(a.m, 1), dtype=np.uint32)
+    v = a.view()
+    _check(lib().flex_order_dfs(C.byref(v), rank.ctypes.data), "flex_order_dfs")
     return rank[: a.m]
 
 

@@ -167,6 +167,13 @@ DataLoaderDeg::DataLoaderDeg(const DataLoader &dl) : DataLoader(dl) {
     adopt_rank(dl, rank, "DEG");
 }
 
+DataLoaderDFS::DataLoaderDFS(const DataLoader &dl) : DataLoader(dl) {
+    std::vector<uint32_t> rank(n);
+    const flex_csr a = dl.csr_view();
+    FLEX_CHECK(flex_order_dfs(&a, rank.data()));
+    adopt_rank(dl, rank, "DFS");
+}
+
 DataLoaderGorder::DataLoaderGorder(const DataLoader &dl) : DataLoader(dl) {
     std::vector<uint32_t> rank(n);
     const flex_csr a = dl.csr_view();

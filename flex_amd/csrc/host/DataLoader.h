@@ -68,6 +68,10 @@ class DataLoaderDeg : public DataLoader {  // DataLoader.cu:657-721
    public:
     explicit DataLoaderDeg(const DataLoader &dl);
 };
+class DataLoaderDFS : public DataLoader {  // DataLoader.cu:324-451
+   public:
+    explicit DataLoaderDFS(const DataLoader &dl);
+};
 class DataLoaderGorder : public DataLoader {  // DataLoader.cu:789-857 (window 3)
    public:
     explicit DataLoaderGorder(const DataLoader &dl);

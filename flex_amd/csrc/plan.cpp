@@ -161,7 +161,7 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
         // pad to a whole number of steps: value 0, B row = the last real one (always a valid address)
         while (e1 > e0 && rec.size() % S != 0) rec.push_back(make_uint2(rec.back().x, 0u));
     };
-    constexpr uint32_t kMaxTasksPerWave = 63;  // kernel hands descriptors out by lane (spmm_v4_kernel)
+    constexpr uint32_t kMaxTasksPerWave = 63;  // kernel hands descriptors out by lane (process_chunk)
     auto open_wave_if_needed = [&]() {
         if (w_task.empty() || wave_cost >= wave_nnz || t_dst.size() - w_task.back() >= kMaxTasksPerWave) {
             w_task.push_back(static_cast<uint32_t>(t_dst.size()));

@@ -95,6 +95,36 @@ int flex_order_rcm(const flex_csr *A, uint32_t *rank) {
     return FLEX_OK;
 }
 
+int flex_order_dfs(const flex_csr *A, uint32_t *rank) {
+    // ≙ DataLoaderDFS (DataLoader.cu:324-395): pre-order numbering of an iterative depth-first search
+    // that starts at vertex 0, follows out-edges in CSR order and restarts at the lowest unvisited vertex.
+    if (!rank) return FLEX_ERR_INVALID;
+    int rc = flex::validate_csr(A);
+    if (rc) return rc;
+    if (A->m != A->n) return FLEX_ERR_INVALID;
+    const uint32_t n = static_cast<uint32_t>(A->m), unseen = 0xFFFFFFFFu;
+    std::fill(rank, rank + n, unseen);
+    std::vector<std::pair<uint32_t, uint32_t>> stack;  // (vertex, next edge)
+    uint32_t next_id = 0;
+    for (uint32_t root = 0; root < n; ++root) {
+        if (rank[root] != unseen) continue;
+        rank[root] = next_id++;
+        stack.emplace_back(root, A->rowPtr[root]);
+        while (!stack.empty()) {
+            auto &top = stack.back();
+            if (top.second == A->rowPtr[top.first + 1]) {
+                stack.pop_back();
+                continue;
+            }
+            const uint32_t v = A->col[top.second++];
+            if (rank[v] != unseen) continue;
+            rank[v] = next_id++;
+            stack.emplace_back(v, A->rowPtr[v]);
+        }
+    }
+    return FLEX_OK;
+}
+
 int flex_order_deg(const flex_csr *A, int descending, uint32_t *rank) {
     if (!rank) return FLEX_ERR_INVALID;
     int rc = flex::validate_csr(A);

@@ -97,27 +97,27 @@ extern "C" int flex_synth_preset(const char *name, int scale, flex_synth_params 
         double alpha;
         int64_t community;
         double p_in, p_near;
-        int gcn;
+        int gcn, directed;
     };
     // shapes: README.md:13-20 (GNN graphs) and SURVEY 8(d) (the two SuiteSparse matrices that
     // data/SuiteSparse/prepare_mtx_data.sh fetches); structure parameters are this project's choice
     static const Preset table[] = {
-        {"amazon", 1569960, 264339468, 2.1, 4096, 0.60, 0.25, 0},
-        {"flickr", 89250, 989006, 2.3, 256, 0.55, 0.25, 1},
-        {"ppi", 14755, 458973, 2.4, 128, 0.60, 0.20, 1},
-        {"pubmed", 19717, 108365, 2.6, 64, 0.60, 0.25, 1},
-        {"reddit", 232965, 23446803, 2.1, 2048, 0.60, 0.25, 1},
-        {"soc-sign-epinions", 131828, 841372, 2.2, 128, 0.40, 0.20, 1},
-        {"wiki-vote", 8297, 103689, 2.2, 0, 0.0, 0.0, 1},
-        {"yelp", 716847, 13954819, 2.2, 512, 0.55, 0.25, 1},
+        {"amazon", 1569960, 264339468, 2.1, 4096, 0.60, 0.25, 0, 0},
+        {"flickr", 89250, 989006, 2.3, 256, 0.55, 0.25, 1, 0},
+        {"ppi", 14755, 458973, 2.4, 128, 0.60, 0.20, 1, 0},
+        {"pubmed", 19717, 108365, 2.6, 64, 0.60, 0.25, 1, 0},
+        {"reddit", 232965, 23446803, 2.1, 2048, 0.60, 0.25, 1, 0},
+        {"soc-sign-epinions", 131828, 841372, 2.2, 128, 0.40, 0.20, 0, 1},
+        {"wiki-vote", 8297, 103689, 2.2, 64, 0.30, 0.20, 0, 1},
+        {"yelp", 716847, 13954819, 2.2, 512, 0.55, 0.25, 1, 0},
     };
     for (size_t i = 0; i < sizeof table / sizeof table[0]; ++i) {
         if (std::strcmp(name, table[i].name) != 0) continue;
         const Preset &t = table[i];
         int64_t nnz = t.nnz;
-        if ((nnz - t.n) & 1) --nnz;  // symmetric + one self loop per row needs nnz - n even
+        if (!t.directed && ((nnz - t.n) & 1)) --nnz;  // symmetric + one self loop per row needs nnz - n even
         *out = flex_synth_params{t.n * scale, nnz * scale, t.alpha, t.community, t.p_in, t.p_near, 8, 1, t.gcn,
-                                 0xF1E0ull + i};
+                                 t.directed, 0xF1E0ull + i};
         return FLEX_OK;
     }
     return FLEX_ERR_INVALID;
@@ -127,8 +127,10 @@ extern "C" int flex_synth_graph(const flex_synth_params *p, flex_host_csr *out) 
     if (!p || !out) return FLEX_ERR_INVALID;
     std::memset(out, 0, sizeof *out);
     const int64_t n = p->n, nnz = p->nnz;
-    if (n <= 0 || n >= INT32_MAX || nnz < n || ((nnz - n) & 1) || nnz >= (int64_t(1) << 32)) return FLEX_ERR_INVALID;
-    const int64_t E = (nnz - n) / 2;
+    const bool directed = p->directed != 0;
+    if (n <= 0 || n >= INT32_MAX || nnz >= (int64_t(1) << 32)) return FLEX_ERR_INVALID;
+    if (directed ? nnz < 0 : (nnz < n || ((nnz - n) & 1))) return FLEX_ERR_INVALID;
+    const int64_t E = directed ? nnz : (nnz - n) / 2;
     if (n < 2 ? E > 0 : static_cast<double>(E) > 0.25 * static_cast<double>(n) * (n - 1)) return FLEX_ERR_INVALID;
     const double alpha = p->alpha > 1.5 ? p->alpha : 2.1;
     Rng rng(mix64(p->seed) ^ 0xF1E0);
@@ -246,19 +248,34 @@ extern "C" int flex_synth_graph(const flex_synth_params *p, flex_host_csr *out) 
         return FLEX_ERR_NOMEM;
     }
     uint32_t *rp = out->rowPtr;
-    for (int64_t i = 0; i < n; ++i) rp[i + 1] = 1;  // self loop
+    // directed stand-ins keep each edge in one direction chosen by a hash of the pair
+    auto flipped = [&](uint64_t key) { return directed && (mix64(key ^ p->seed) & 1); };
+    if (!directed)
+        for (int64_t i = 0; i < n; ++i) rp[i + 1] = 1;  // self loop
     for (uint64_t key : edges) {
-        ++rp[relabel[key >> 32] + 1];
-        ++rp[relabel[key & 0xFFFFFFFFu] + 1];
+        const uint32_t a = relabel[key >> 32], b = relabel[key & 0xFFFFFFFFu];
+        if (!directed) {
+            ++rp[a + 1];
+            ++rp[b + 1];
+        } else {
+            ++rp[(flipped(key) ? b : a) + 1];
+        }
     }
     for (int64_t i = 0; i < n; ++i) rp[i + 1] += rp[i];
     {
         std::vector<uint32_t> cur(rp, rp + n);
-        for (int64_t i = 0; i < n; ++i) out->col[cur[i]++] = static_cast<uint32_t>(i);
+        if (!directed)
+            for (int64_t i = 0; i < n; ++i) out->col[cur[i]++] = static_cast<uint32_t>(i);
         for (uint64_t key : edges) {
             const uint32_t a = relabel[key >> 32], b = relabel[key & 0xFFFFFFFFu];
-            out->col[cur[a]++] = b;
-            out->col[cur[b]++] = a;
+            if (!directed) {
+                out->col[cur[a]++] = b;
+                out->col[cur[b]++] = a;
+            } else if (flipped(key)) {
+                out->col[cur[b]++] = a;
+            } else {
+                out->col[cur[a]++] = b;
+            }
         }
     }
     edges = std::vector<uint64_t>();
@@ -272,7 +289,7 @@ extern "C" int flex_synth_graph(const flex_synth_params *p, flex_host_csr *out) 
             for (uint32_t z = rp[i]; z < rp[i + 1]; ++z) {
                 const uint32_t j = out->col[z];
                 if (p->gcn_norm) {
-                    out->vals[z] = static_cast<float>(1.0 / std::sqrt(di * (rp[j + 1] - rp[j])));
+                    out->vals[z] = static_cast<float>(1.0 / std::sqrt(di * std::max<double>(1.0, rp[j + 1] - rp[j])));
                 } else {  // U(-1,1), symmetric in (i,j)
                     const uint64_t a = std::min<uint64_t>(i, j), bb = std::max<uint64_t>(i, j);
                     const uint64_t h = mix64(vseed ^ (a << 32 | bb));
@@ -283,10 +300,24 @@ extern "C" int flex_synth_graph(const flex_synth_params *p, flex_host_csr *out) 
     });
     out->uni_nb = 0;
     for (int64_t i = 0; i < n; ++i) out->uni_nb += (rp[i + 1] - rp[i] == 1);
-    // symmetric with symmetric values and a self loop on every row, by construction
-    out->n_edges_one_way = out->n_edges_asymmetric = 0;
-    out->n_nodes_z_out = out->n_nodes_z_in = out->n_nodes_z_deg = 0;
-    out->is_directed = 0;
     out->c = 100;
+    if (!directed) {  // symmetric with symmetric values and a self loop on every row, by construction
+        out->n_edges_one_way = out->n_edges_asymmetric = 0;
+        out->n_nodes_z_out = out->n_nodes_z_in = out->n_nodes_z_deg = 0;
+        out->is_directed = 0;
+        return FLEX_OK;
+    }
+    // one direction per pair: every edge is one-way; zero-degree counts from the two degree vectors
+    out->n_edges_one_way = nnz;
+    out->n_edges_asymmetric = 0;
+    out->is_directed = nnz > 0;
+    std::vector<uint8_t> has_in(static_cast<size_t>(n), 0);
+    for (int64_t z = 0; z < nnz; ++z) has_in[out->col[z]] = 1;
+    for (int64_t i = 0; i < n; ++i) {
+        const bool z_out = rp[i + 1] == rp[i], z_in = !has_in[i];
+        out->n_nodes_z_out += z_out;
+        out->n_nodes_z_in += z_in;
+        out->n_nodes_z_deg += (z_out && z_in);
+    }
     return FLEX_OK;
 }

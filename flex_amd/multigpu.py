@@ -60,7 +60,7 @@ def make_shard(a: "_b.HostCsr", k: int, rank: int, world: int, order: str = "clu
     if order == "natural":
         vo, ap = None, a
     else:
-        rank_arr = {"rcm": _b.order_rcm, "cluster": _b.order_cluster, "deg": _b.order_deg, "gorder": _b.order_gorder}[order](a)
+        rank_arr = {"rcm": _b.order_rcm, "cluster": _b.order_cluster, "deg": _b.order_deg, "gorder": _b.order_gorder, "dfs": _b.order_dfs}[order](a)
         vo, ap = _b.perm_csr(a, rank_arr)
     bounds = _b.shard_rows(ap, k, world)
     return RowShard(ap, vo, bounds, rank, world)

@@ -147,6 +147,9 @@ int flex_order_rcm(const flex_csr *A, uint32_t *rank);
  * with an isolated vertex (the reference cannot order one either, unitheap.cu:35-38). */
 int flex_order_gorder(const flex_csr *A, uint32_t window, uint32_t *rank);
 
+/* ≙ the ordering of DataLoaderDFS (DataLoader.cu:324-395): depth-first pre-order from vertex 0. */
+int flex_order_dfs(const flex_csr *A, uint32_t *rank);
+
 /* ≙ order_deg(h, desc) (order_deg.cu:19-45): rank by in+out degree, ties by vertex id. */
 int flex_order_deg(const flex_csr *A, int descending, uint32_t *rank);
 
@@ -178,6 +181,8 @@ typedef struct flex_synth_params {
     int32_t near_window; /* communities on either side counted as "near" */
     int32_t shuffle;     /* 1: random vertex relabel so the natural order is not banded */
     int32_t gcn_norm;    /* 1: vals = 1/sqrt(d_i d_j) (pubmed-like); 0: U(-1,1) */
+    int32_t directed;    /* 1: every edge kept in ONE random direction, no self loops, so nnz = #edges and
+                            rows may be empty (the SuiteSparse stand-ins); 0: symmetric + self loops */
     uint64_t seed;
 } flex_synth_params;
 int flex_synth_graph(const flex_synth_params *p, flex_host_csr *out);

@@ -59,6 +59,8 @@ def lib():
         L.oracle_order_rcm.restype = C.c_int
         L.oracle_order_gorder.argtypes = [C.c_int64, u32p, u32p, C.c_uint64, u64p]
         L.oracle_order_gorder.restype = C.c_int
+        L.oracle_order_dfs.argtypes = [C.c_int64, u32p, u32p, u64p]
+        L.oracle_order_dfs.restype = C.c_int
         L.oracle_perm_csr.argtypes = [C.c_int64, u32p, u32p, f32p, u64p, i32p, u32p, u32p, f32p]
         _lib = L
     return _lib
@@ -150,6 +152,16 @@ def order_gorder(rowPtr, col, window: int = 3) -> np.ndarray:
     rc = lib().oracle_order_gorder(n, _p(rowPtr, C.c_uint32), _p(col, C.c_uint32), window, _p(rank, C.c_uint64))
     if rc:
         raise RuntimeError(f"oracle_order_gorder failed: {rc}")
+    return rank[:n]
+
+
+def order_dfs(rowPtr, col) -> np.ndarray:
+    rowPtr, col = _u32(rowPtr), _u32(col)
+    n = len(rowPtr) - 1
+    rank = np.empty(max(n, 1), dtype=np.uint64)
+    rc = lib().oracle_order_dfs(n, _p(rowPtr, C.c_uint32), _p(col, C.c_uint32), _p(rank, C.c_uint64))
+    if rc:
+        raise RuntimeError(f"oracle_order_dfs failed: {rc}")
     return rank[:n]
 
 

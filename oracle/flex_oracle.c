@@ -668,3 +668,35 @@ int oracle_order_gorder(int64_t n, const uint32_t *rowPtr, const uint32_t *col, 
     free(order); free(isolates); free(tmp_old); free(tmp_new); free(fill); free(g.cd); free(g.adj); free(rank_rcm);
     return rc;
 }
+
+/* --------------------------------------------------------------------- DFS */
+/* DataLoaderDFS, DataLoader.cu:324-395: iterative DFS from vertex 0 over the CSR's out-edges in
+ * stored order, new ids in discovery order (rowPtr grows by one entry per discovery, :358-372),
+ * next root = next vertex without an id (:377-379).  rank[old] = new. */
+int oracle_order_dfs(int64_t n, const uint32_t *rowPtr, const uint32_t *col, uint64_t *rank) {
+    uint8_t *seen = (uint8_t *)calloc((size_t)n + 1, 1);
+    uint32_t *stack_v = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n + 1));
+    uint32_t *stack_e = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n + 1));
+    if (!seen || !stack_v || !stack_e) return -ENOMEM;
+    uint64_t next_id = 0;
+    for (int64_t root = 0; root < n; ++root) {
+        if (seen[root]) continue;
+        int64_t sp = 0;
+        seen[root] = 1;
+        rank[root] = next_id++;
+        stack_v[sp] = (uint32_t)root;
+        stack_e[sp++] = rowPtr[root];
+        while (sp > 0) {
+            const uint32_t u = stack_v[sp - 1];
+            while (stack_e[sp - 1] < rowPtr[u + 1] && seen[col[stack_e[sp - 1]]]) stack_e[sp - 1]++;
+            if (stack_e[sp - 1] == rowPtr[u + 1]) { sp--; continue; }
+            const uint32_t v = col[stack_e[sp - 1]++];
+            seen[v] = 1;
+            rank[v] = next_id++;
+            stack_v[sp] = v;
+            stack_e[sp++] = rowPtr[v];
+        }
+    }
+    free(seen); free(stack_v); free(stack_e);
+    return 0;
+}

@@ -76,6 +76,9 @@ int oracle_order_rcm(int64_t n, const uint32_t *rowPtr, const uint32_t *col, uin
  * (DataLoader.cu:808). */
 int oracle_order_gorder(int64_t n, const uint32_t *rowPtr, const uint32_t *col, uint64_t window, uint64_t *rank);
 
+/* DataLoaderDFS ordering, DataLoader.cu:324-395: depth-first discovery order from vertex 0. */
+int oracle_order_dfs(int64_t n, const uint32_t *rowPtr, const uint32_t *col, uint64_t *rank);
+
 /* DataLoaderRcm / DataLoaderGorder body, DataLoader.cu:741-779 / 815-850: given
  * rank[old]=new, build vo_mp[new]=old and the permuted CSR with columns mapped and
  * sorted ascending per row. Output arrays are caller-allocated (same sizes). */

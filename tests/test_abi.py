@@ -179,3 +179,14 @@ def test_cluster_and_deg_orders_are_permutations_with_locality():
     assert near(clu) > 3 * near(np.arange(g.n)) and near(clu) > 0.3
     d = np.diff(g.rowPtr.astype(np.int64)) * 2 - 1  # in+out degree of a symmetric graph with self loops
     assert np.all(np.diff(d[np.argsort(deg)]) <= 0)  # order_deg(desc): degrees descend along the new order
+
+
+def test_dfs_order_equals_oracle_and_is_a_preorder():
+    for name in ("pubmed.csv", "a_mat.csv"):
+        a = flex_amd.csv_load(os.path.join(GOLDEN, name))
+        r = flex_amd.order_dfs(a)
+        assert np.array_equal(r.astype(np.uint64), oracle.order_dfs(a.rowPtr, a.col))
+        assert sorted(r.tolist()) == list(range(a.n)) and r[0] == 0
+    # a path 0->2->1 plus an unreachable vertex 3: discovery order 0,2,1 then the next root 3
+    p = flex_amd.HostCsr([0, 1, 1, 2, 2], [2, 1], [1.0, 1.0])
+    assert flex_amd.order_dfs(p).tolist() == [0, 2, 1, 3]

@@ -243,7 +243,7 @@ def test_cxx_host_mirror_cli_pubmed_and_amat():
         assert out.returncode == 0, out.stdout + out.stderr
         rows = [json.loads(line) for line in out.stdout.splitlines() if line.startswith("{")]
         assert {(r["ord"], r["schedule"]) for r in rows} >= {("OVO", "natural"), ("OVO", "cluster"), ("RCM", "natural"),
-                                                             ("RBT", "natural"), ("DEG", "natural"), ("GOR", "natural")}
+                                                             ("RBT", "natural"), ("DEG", "natural"), ("GOR", "natural"), ("DFS", "natural")}
         assert all(r["errs"] == 0 for r in rows)
     assert "hipSPARSE setup" in out.stdout
 
