@@ -88,8 +88,35 @@ constexpr int kWindowRecs = 256;  // records staged per wave and window (2 KiB o
 #define FLEX_STAMP(i) do {} while (0)
 #endif
 
+// Records of a window: lane l holds records l, l+64, l+128, l+192 (coalesced 512-B loads).
+struct RecRegs {
+    uint2 r[kWindowRecs / 64];
+};
+
+__device__ __forceinline__ RecRegs load_window(const uint2 *__restrict__ rec, uint32_t wz, uint32_t wn, int lane) {
+    RecRegs w;
+#pragma unroll
+    for (int i = 0; i < kWindowRecs / 64; ++i) {
+        const uint32_t idx = i * 64 + lane;
+        w.r[i] = idx < wn ? rec[wz + idx] : make_uint2(0u, 0u);
+    }
+    return w;
+}
+
+__device__ __forceinline__ void store_window(uint2 *my_lds, const RecRegs &w, uint32_t wn, int lane) {
+#pragma unroll
+    for (int i = 0; i < kWindowRecs / 64; ++i) {
+        const uint32_t idx = i * 64 + lane;
+        if (idx < wn) my_lds[idx] = w.r[i];
+    }
+}
+
+// All the work of one chunk once its header {first task, #tasks, first record, end record} and its
+// task descriptors (lane i: t_beg[t0+i], t_dst[t0+i]) are in registers.  `staged`: the first
+// window of records is already in my_lds (for callers that prefetch it; unused today).
 template <int G, bool OFF32, int U>
-__device__ __forceinline__ void process_chunk(const PlanView &p, uint32_t c, uint2 *my_lds, const char *__restrict__ Bb,
+__device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint32_t my_beg, uint32_t my_dst,
+                                              bool staged, uint2 *my_lds, const char *__restrict__ Bb,
                                               float *__restrict__ C, int lane, int c0, bool col_ok
 #ifdef FLEX_TRACE
                                               , uint64_t *phase, uint64_t &last_
@@ -102,15 +129,7 @@ __device__ __forceinline__ void process_chunk(const PlanView &p, uint32_t c, uin
     const uint64_t row_bytes = static_cast<uint64_t>(k) * 4u;
     const uint2 *__restrict__ rec = p.rec;
 
-    // A chunk holds at most 63 tasks (planner invariant): fetch all descriptors with one
-    // coalesced load per array and hand them out with v_readlane, so no row waits on a
-    // dependent descriptor load.
-    // The chunk header carries the record range too, so the record fetch below does not wait
-    // for the task descriptors: header -> {descriptors, records} -> gathers.
-    const uint4 hdr = p.chunk[c];  // {first task, #tasks, first record, end record}
-    const uint32_t t0 = hdr.x, nt = hdr.y, zb = hdr.z, ze = hdr.w;
-    const uint32_t my_beg = (static_cast<uint32_t>(lane) <= nt) ? p.t_beg[t0 + lane] : 0u;
-    const uint32_t my_dst = (static_cast<uint32_t>(lane) < nt) ? p.t_dst[t0 + lane] : 0u;
+    const uint32_t nt = hdr.y, zb = hdr.z, ze = hdr.w;
     FLEX_STAMP(0);  // descriptors
 
     uint32_t ti = 0;                                          // current task
@@ -119,9 +138,11 @@ __device__ __forceinline__ void process_chunk(const PlanView &p, uint32_t c, uin
     float4 piece_sum = {0.f, 0.f, 0.f, 0.f};
     uint32_t piece_dst = 0;  // kPartialFlag | slot once this chunk turned out to be a piece of a split row
 
-    // write out every task that ends at stream position `pos` (several when rows are empty)
-    auto drain = [&](uint32_t pos) {
-        while (ti < nt && row_end == pos) {
+    // Write out the task that ends at the current stream position (and any empty rows behind it).
+    // row_end is kept at ~0 once the chunk's tasks are exhausted, so the per-step test in the hot
+    // loop is ONE scalar compare.
+    auto flush = [&](uint32_t pos) {
+        do {
             float4 r = acc;
 #pragma unroll
             for (int off = G; off < 32; off <<= 1) {
@@ -138,7 +159,11 @@ __device__ __forceinline__ void process_chunk(const PlanView &p, uint32_t c, uin
             }
             const uint32_t dst = __builtin_amdgcn_readlane(my_dst, ti);
             if (!(dst & kPartialFlag)) {
+#ifdef FLEX_ABL_NOSTORE  // timing-only ablation: the store is kept in the code but never executes
+                if (slot == 0 && col_ok && p.k < 0) {
+#else
                 if (slot == 0 && col_ok) {
+#endif
                     const v4f val = {r.x, r.y, r.z, r.w};
                     __builtin_nontemporal_store(val, reinterpret_cast<v4f *>(C + static_cast<uint64_t>(dst) * k + c0));
                 }
@@ -150,37 +175,64 @@ __device__ __forceinline__ void process_chunk(const PlanView &p, uint32_t c, uin
             }
             acc = {0.f, 0.f, 0.f, 0.f};
             ++ti;
-            row_end = __builtin_amdgcn_readlane(my_beg, ti + 1 <= nt ? ti + 1 : nt);
-        }
+            row_end = ti < nt ? __builtin_amdgcn_readlane(my_beg, ti + 1) : 0xFFFFFFFFu;
+        } while (row_end == pos);
     };
-    drain(zb);  // leading empty rows
+    if (nt == 0) row_end = 0xFFFFFFFFu;
+    if (row_end == zb) flush(zb);  // leading empty rows
 
+    uint32_t pos = zb;  // stream position after the steps consumed so far
     for (uint32_t wz = zb; wz < ze; wz += kWindowRecs) {
         const uint32_t wn = min(static_cast<uint32_t>(kWindowRecs), ze - wz);
         // stage this window's records: coalesced 512-B loads, one ds_write_b64 per lane and load
-#pragma unroll
-        for (int i = 0; i < kWindowRecs / 64; ++i) {
-            const uint32_t idx = i * 64 + lane;
-            if (idx < wn) my_lds[idx] = rec[wz + idx];
-        }
+        if (!(staged && wz == zb)) store_window(my_lds, load_window(rec, wz, wn, lane), wn, lane);
         FLEX_STAMP(1);  // records -> LDS
         const uint32_t nsteps = wn / S;  // rows are padded to multiples of S
-        for (uint32_t j = 0; j < nsteps; j += U) {
+        const uint2 *lds_slot = my_lds + slot;
+        uint32_t j = 0;
+        for (; j + U <= nsteps; j += U) {  // full blocks: no bound checks in the instruction stream
             uint2 r[U];
             float4 b[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) r[u] = my_lds[min(j + u, nsteps - 1) * S + slot];
+            for (int u = 0; u < U; ++u) r[u] = lds_slot[(j + u) * S];
+#ifdef FLEX_ABL_NOGATHER  // timing-only ablation: no B traffic at all, values faked from the record
+#pragma unroll
+            for (int u = 0; u < U; ++u) b[u] = make_float4(as_f32(r[u].x), as_f32(r[u].y), 1.f, 2.f);
+#else
 #pragma unroll
             for (int u = 0; u < U; ++u) b[u] = gather4<OFF32>(Bb, r[u].x, lane_off, row_bytes);
+#endif
             FLEX_STAMP(2);  // gathers
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                fma4(acc, as_f32(r[u].y), b[u]);
+                pos += S;
+                if (pos == row_end) flush(pos);
+            }
+            FLEX_STAMP(3);  // fma + row flushes
+        }
+        if (j < nsteps) {  // the window's last, partial block
+            uint2 r[U];
+            float4 b[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) r[u] = lds_slot[min(j + u, nsteps - 1) * S];
+#ifdef FLEX_ABL_NOGATHER
+#pragma unroll
+            for (int u = 0; u < U; ++u) b[u] = make_float4(as_f32(r[u].x), as_f32(r[u].y), 1.f, 2.f);
+#else
+#pragma unroll
+            for (int u = 0; u < U; ++u) b[u] = gather4<OFF32>(Bb, r[u].x, lane_off, row_bytes);
+#endif
+            FLEX_STAMP(2);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (j + u < nsteps) {  // wave-uniform
                     fma4(acc, as_f32(r[u].y), b[u]);
-                    drain(wz + (j + u + 1) * S);
+                    pos += S;
+                    if (pos == row_end) flush(pos);
                 }
             }
-            FLEX_STAMP(3);  // fma + row flushes
+            FLEX_STAMP(3);
         }
     }
     if (piece_dst & kPartialFlag) {
@@ -243,23 +295,29 @@ __device__ __forceinline__ void process_chunk(const PlanView &p, uint32_t c, uin
 // contiguous eighth of the schedule with ONE cursor, and its resident waves form a sliding
 // window over neighbouring rows whose shared B rows stay in that XCD's 4 MiB L2.  (A
 // persistent variant with per-XCD ticket queues was measured and rejected: DESIGN.md 3.4.)
-template <int G, bool OFF32, int U>
-__global__ __launch_bounds__(256) void spmm_flat_kernel(PlanView p, const float *__restrict__ B,
-                                                        float *__restrict__ C) {
-    __shared__ uint2 lds_rec[kWavesPerBlock][kWindowRecs];
+template <int G, bool OFF32, int U, int WPB>
+__global__ __launch_bounds__(64 * WPB) void spmm_flat_kernel(PlanView p, const float *__restrict__ B,
+                                                             float *__restrict__ C) {
+    __shared__ uint2 lds_rec[WPB][kWindowRecs];
     const int lane = threadIdx.x & 63;
     const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t cpx = gridDim.x / kXcds;  // gridDim.x % 8 == 0
     const uint32_t bid = p.xcd_remap ? (blockIdx.x % kXcds) * cpx + (blockIdx.x / kXcds) : blockIdx.x;
-    const uint32_t chunk = bid * kWavesPerBlock + wib;
+    const uint32_t chunk = bid * WPB + wib;
     if (chunk >= p.n_chunks) return;
+#ifdef FLEX_ABL_EMPTY  // timing-only ablation: dispatch + one header load per wave, nothing else
+    if (p.chunk[chunk].y != 0xFFFFFFFFu) return;
+#endif
     const int c0 = blockIdx.y * (4 * G) + (lane % G) * 4;  // first of this lane's 4 columns
     const bool col_ok = c0 < p.k;                            // k % 4 == 0 on this path
 #ifdef FLEX_TRACE  // diagnostic build only (tools/trace.py)
     const uint64_t trace_t0 = __builtin_amdgcn_s_memrealtime();
     uint64_t phase[5] = {0, 0, 0, 0, 0};
     uint64_t last_ = trace_t0;
-    process_chunk<G, OFF32, U>(p, chunk, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok, phase, last_);
+    const uint4 hdr = p.chunk[chunk];
+    const uint32_t my_beg = (static_cast<uint32_t>(lane) <= hdr.y) ? p.t_beg[hdr.x + lane] : 0u;
+    const uint32_t my_dst = (static_cast<uint32_t>(lane) < hdr.y) ? p.t_dst[hdr.x + lane] : 0u;
+    compute_chunk<G, OFF32, U>(p, hdr, my_beg, my_dst, false, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok, phase, last_);
     if (lane == 0 && p.trace != nullptr) {
         uint64_t *log = p.trace + static_cast<uint64_t>(chunk) * 12;
         log[0] = xcc_id();
@@ -271,7 +329,13 @@ __global__ __launch_bounds__(256) void spmm_flat_kernel(PlanView p, const float 
         for (int i = 0; i < 5; ++i) log[6 + i] = phase[i];
     }
 #else
-    process_chunk<G, OFF32, U>(p, chunk, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok);
+    // A chunk holds at most 63 tasks (planner invariant): all descriptors come with one coalesced
+    // load per array and are handed out with v_readlane; the header carries the record range, so
+    // the record fetch does not wait for them: header -> {descriptors, records} -> gathers.
+    const uint4 hdr = p.chunk[chunk];
+    const uint32_t my_beg = (static_cast<uint32_t>(lane) <= hdr.y) ? p.t_beg[hdr.x + lane] : 0u;
+    const uint32_t my_dst = (static_cast<uint32_t>(lane) < hdr.y) ? p.t_dst[hdr.x + lane] : 0u;
+    compute_chunk<G, OFF32, U>(p, hdr, my_beg, my_dst, false, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok);
 #endif
 }
 
@@ -369,10 +433,13 @@ template <int G, bool OFF32, int U>
 int launch_v4(const PlanView &v, const float *dB, float *dC, hipStream_t s) {
     // persistent grid: enough workgroups to fill every CU (8 x 256 threads each), fewer for tiny plans;
     // surplus workgroups find the queues empty and leave at once
+    // 2 or 8 waves per workgroup measured the same as 4 (the launch is not dispatch-bound: an empty
+    // kernel over the same grid takes 3.4 us), so the template parameter stays at kWavesPerBlock
     uint32_t nblk = (v.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
     nblk = (nblk + kXcds - 1) / kXcds * kXcds;
     const uint32_t ktiles = (v.k + 4 * G - 1) / (4 * G);
-    hipLaunchKernelGGL((spmm_flat_kernel<G, OFF32, U>), dim3(nblk, ktiles), dim3(256), v.lds_extra, s, v, dB, dC);
+    hipLaunchKernelGGL((spmm_flat_kernel<G, OFF32, U, kWavesPerBlock>), dim3(nblk, ktiles), dim3(64 * kWavesPerBlock),
+                       v.lds_extra, s, v, dB, dC);
     FLEX_HIP_TRY(hipGetLastError());
     return FLEX_OK;
 }
