@@ -187,6 +187,12 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
         // stage this window's records: coalesced 512-B loads, one ds_write_b64 per lane and load
         if (!(staged && wz == zb)) store_window(my_lds, load_window(rec, wz, wn, lane), wn, lane);
         FLEX_STAMP(1);  // records -> LDS
+#ifdef FLEX_ABL_STAGEONLY  // timing-only ablation: header, descriptors and records fetched, then leave
+        if (p.k > 0) {
+            if (lane == 0 && my_lds[wn - 1].x == 0xFFFFFFFEu) C[0] = as_f32(my_beg + my_dst);
+            return;
+        }
+#endif
         const uint32_t nsteps = wn / S;  // rows are padded to multiples of S
         const uint2 *lds_slot = my_lds + slot;
         uint32_t j = 0;
@@ -207,7 +213,9 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
             for (int u = 0; u < U; ++u) {
                 fma4(acc, as_f32(r[u].y), b[u]);
                 pos += S;
+#ifndef FLEX_ABL_NOFLUSH  // timing-only ablation: rows are never written out (one flush at the very end)
                 if (pos == row_end) flush(pos);
+#endif
             }
             FLEX_STAMP(3);  // fma + row flushes
         }
@@ -229,12 +237,17 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
                 if (j + u < nsteps) {  // wave-uniform
                     fma4(acc, as_f32(r[u].y), b[u]);
                     pos += S;
+#ifndef FLEX_ABL_NOFLUSH
                     if (pos == row_end) flush(pos);
+#endif
                 }
             }
             FLEX_STAMP(3);
         }
     }
+#ifdef FLEX_ABL_NOFLUSH
+    if (nt > 0) { ti = nt - 1; flush(0xFFFFFFFEu); }  // pos != the ~0 sentinel, or the do-while never ends
+#endif
     if (piece_dst & kPartialFlag) {
         const float4 r = piece_sum;
         const uint32_t ps = piece_dst & ~kPartialFlag;

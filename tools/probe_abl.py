@@ -28,4 +28,4 @@ print(f"{os.path.basename(sys.argv[1]):26s} {name} k={k} fold={fold:6d}: {best:7
 ''' % ROOT
 for lib in sys.argv[1].split(","):
     for fold in (1024, 0):
-        subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "flex_amd", "lib", lib), sys.argv[2], sys.argv[3], str(fold)], check=True)
+        subprocess.run([sys.executable, "-c", code, os.path.join(ROOT, "flex_amd", "lib", lib), sys.argv[2], sys.argv[3], str(fold)], check=True, timeout=90)
