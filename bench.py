@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + FLEX_BENCH_DEVICE=0 rehearses the N>1 path on a one-GPU box (not a measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vendor", action="store_true", help="skip the hipSPARSE side-by-side (N=1 only)")
     ap.add_argument("--check", action="store_true", help="verify rank 0's shard against the oracle (small workloads)")
     return ap.parse_args()
 
@@ -184,6 +185,8 @@ def main():
         }
         if ok is not None:
             out["check"] = ok
+        if world == 1 and not args.no_vendor:
+            out["hipsparse"] = vendor_baseline(a, k, B, C)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, k, B)
         print(json.dumps(out), flush=True)
@@ -199,6 +202,44 @@ def _pmc_traffic(args, world):
         d = json.load(open(p))
         return d.get(f"{args.workload}_k{args.k}_{args.order}_n{world}")
     except Exception:
+        return None
+
+
+def vendor_baseline(a, k, B, C):
+    """hipSPARSE SpMM (CSR_ALG3, row-major; the reference's cuSpmm protocol: 5 warm-up + 10 timed,
+    flex.cu:5766-5789) on the same device-resident operands -- a reported side-by-side, not the metric."""
+    import ctypes as ct
+
+    import torch
+
+    import flex_amd
+    try:
+        V = ct.CDLL(os.path.join(os.path.dirname(flex_amd.lib_path()), "libflex_vendor.so"))
+        V.flex_vendor_spmm_create.argtypes = [ct.POINTER(ct.c_void_p), ct.c_int32, ct.c_int32, ct.c_int64, ct.c_void_p,
+                                              ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_void_p]
+        V.flex_vendor_spmm_run.argtypes = [ct.c_void_p, ct.c_void_p]
+        V.flex_vendor_spmm_destroy.argtypes = [ct.c_void_p]
+        rp = torch.from_numpy(a.rowPtr.astype(np.int32)).cuda()
+        col = torch.from_numpy(a.col.astype(np.int32)).cuda()
+        val = torch.from_numpy(a.vals).cuda()
+        h = ct.c_void_p()
+        if V.flex_vendor_spmm_create(ct.byref(h), a.m, a.n, a.nnz, rp.data_ptr(), col.data_ptr(), val.data_ptr(), k,
+                                     B.data_ptr(), C.data_ptr()) != 0:
+            return None
+        s = torch.cuda.current_stream().cuda_stream
+        for _ in range(5):
+            V.flex_vendor_spmm_run(h, s)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            V.flex_vendor_spmm_run(h, s)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        V.flex_vendor_spmm_destroy(h)
+        return {"value": round(2.0 * a.nnz * k / (ms * 1e-3) / 1e9, 2), "unit": "GFLOPS", "ms_per_step": round(ms, 6),
+                "algorithm": "hipsparseSpMM CSR_ALG3, row-major B/C, alpha=1, beta=0 (cuSpmm, flex.cu:5717-5804)"}
+    except OSError:
         return None
 
 

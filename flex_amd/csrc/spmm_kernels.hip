@@ -57,6 +57,20 @@ __device__ __forceinline__ void fma4(float4 &acc, float v, const float4 &b) {
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
+// x[l] + x[l ^ 8]: the partner sits in the same 16-lane row, 8 lanes over: DPP row_ror:8 (pure VALU).
+__device__ __forceinline__ float xor8_sum(float x) {
+    const int u = __float_as_int(x);
+    return x + __int_as_float(__builtin_amdgcn_update_dpp(u, u, 0x128 /* row_ror:8 */, 0xF, 0xF, false));
+}
+
+// x[l] + x[l ^ 16]: v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the
+// even rows of its second; fed (x, x) the two results hold {row0,row0,row2,row2} and {row1,row1,row3,row3}.
+__device__ __forceinline__ float xor16_sum(float x) {
+    const uint32_t u = __float_as_uint(x);
+    const auto sw = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
+
 // x[l] + x[l ^ 32] in every lane.  v_permlane32_swap exchanges the upper half of its first
 // operand with the lower half of its second; fed (x, x) it yields {lo,lo} and {hi,hi}.
 __device__ __forceinline__ float xor32_sum(float x) {
@@ -144,14 +158,21 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
     auto flush = [&](uint32_t pos) {
         do {
             float4 r = acc;
-#pragma unroll
-            for (int off = G; off < 32; off <<= 1) {
-                r.x += __shfl_xor(r.x, off);
-                r.y += __shfl_xor(r.y, off);
-                r.z += __shfl_xor(r.z, off);
-                r.w += __shfl_xor(r.w, off);
+            // combine the S = 64/G slots of the row without touching the LDS: DPP within a 16-lane row,
+            // v_permlane16_swap across rows, v_permlane32_swap across the wave halves
+            if constexpr (G <= 8) {
+                r.x = xor8_sum(r.x);
+                r.y = xor8_sum(r.y);
+                r.z = xor8_sum(r.z);
+                r.w = xor8_sum(r.w);
             }
-            if constexpr (G <= 32) {  // lanes l and l^32: one v_permlane32_swap per component, no LDS round trip
+            if constexpr (G <= 16) {
+                r.x = xor16_sum(r.x);
+                r.y = xor16_sum(r.y);
+                r.z = xor16_sum(r.z);
+                r.w = xor16_sum(r.w);
+            }
+            if constexpr (G <= 32) {
                 r.x = xor32_sum(r.x);
                 r.y = xor32_sum(r.y);
                 r.z = xor32_sum(r.z);

@@ -307,3 +307,27 @@ def test_in_launch_split_row_reduction_is_stable_under_repetition():
     torch.cuda.synchronize()
     assert torch.equal(C, ref) and torch.equal(c2, r2)
     assert oracle.rescheck(ref.cpu().numpy(), r2.cpu().numpy(), a.rowPtr)[0] == 0
+
+
+def test_bench_json_contract():
+    """bench.py prints exactly one JSON line with the contract's keys, a roofline object and a CPU baseline."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "3", "--workload", "pubmed",
+                          "--k", "32", "--check"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 20 and j["dtype"] == "f32" and j["vs_baseline"] is None
+    assert j["check"]["mismatches"] == 0
+    assert set(j["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert abs(j["roofline"]["frac"] - j["roofline"]["achieved"] / j["roofline"]["peak"]) < 1e-3
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] >= 1
+    assert abs(j["value"] - 2 * j["config"]["nnz"] * j["config"]["k"] / (j["ms_per_step"] * 1e-3) / 1e9) < 0.01 * j["value"]
+    assert j["hipsparse"]["value"] > 0
