@@ -331,3 +331,32 @@ def test_bench_json_contract():
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] >= 1
     assert abs(j["value"] - 2 * j["config"]["nnz"] * j["config"]["k"] / (j["ms_per_step"] * 1e-3) / 1e9) < 0.01 * j["value"]
     assert j["hipsparse"]["value"] > 0
+
+
+def test_b_larger_than_4GiB_uses_64bit_row_addressing():
+    """n*k*4 > 2^32: records carry column ids instead of 32-bit byte offsets (OFF32 = false kernels)."""
+    m, n, k = 1500, 2_200_000, 512
+    free, _ = torch.cuda.mem_get_info()
+    if free < 12 * (1 << 30):
+        pytest.skip("needs ~5 GiB of HBM for B")
+    rng = np.random.default_rng(123)
+    deg = rng.integers(0, 40, size=m)
+    deg[7] = 3000  # one split row
+    rp = np.zeros(m + 1, dtype=np.int64)
+    np.cumsum(deg, out=rp[1:])
+    col = rng.integers(0, n, size=rp[-1]).astype(np.uint32)
+    col[:64] = n - 1 - np.arange(64)  # make sure the top of the address range is touched
+    a = flex_amd.HostCsr(rp.astype(np.uint32), col, rng.uniform(-1, 1, rp[-1]).astype(np.float32), n=n)
+    i = torch.arange(n, device="cuda", dtype=torch.float32).unsqueeze(1)
+    j = torch.arange(k, device="cuda", dtype=torch.float32).unsqueeze(0)
+    B = torch.sin(i * 0.37 + j * 0.11)  # cheap, non-trivial, reproducible on the host from the device copy
+    assert B.numel() * 4 > (1 << 32)
+    p = Plan(a, k)
+    C = p(B)
+    torch.cuda.synchronize()
+    used = np.unique(col)
+    Bh_rows = B[torch.from_numpy(used.astype(np.int64)).cuda()].cpu().numpy()
+    remap = np.searchsorted(used, col).astype(np.uint32)  # oracle on the compacted B (same arithmetic)
+    gold = oracle.spmm(a.rowPtr, remap, a.vals, Bh_rows, nthreads=8)
+    cnt, max_err, _, _ = oracle.rescheck(gold, C.cpu().numpy(), a.rowPtr)
+    assert cnt == 0, (cnt, max_err)
