@@ -16,6 +16,10 @@ from .binding import (  # noqa: F401
     Plan,
     build,
     csv_load,
+    csv_save,
+    csr_load_bin,
+    csr_save_bin,
+    mtx_load,
     fill_dense_rand,
     gather_rows,
     lib,

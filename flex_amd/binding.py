@@ -60,7 +60,8 @@ class _SynthParams(C.Structure):  # flex_synth_params
 # every symbol include/flex_spmm.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = [
     "flex_plan_create", "flex_plan_create_mapped", "flex_plan_create_rows", "flex_spmm",
-    "flex_plan_destroy", "flex_plan_get_info", "flex_gather_rows", "flex_csv_load",
+    "flex_plan_destroy", "flex_plan_get_info", "flex_gather_rows", "flex_csv_load", "flex_mtx_load",
+    "flex_csv_save", "flex_csr_save_bin", "flex_csr_load_bin",
     "flex_host_csr_free", "flex_fill_dense_rand", "flex_order_rcm", "flex_order_cluster", "flex_order_gorder", "flex_perm_csr",
     "flex_order_deg", "flex_order_dfs", "flex_shard_rows", "flex_synth_graph", "flex_synth_preset", "flex_strerror", "flex_last_hip_error",
     "flex_last_hip_error_string", "flex_abi_version",
@@ -105,6 +106,10 @@ def lib():
         L.flex_plan_get_info.argtypes = [vp, C.POINTER(_PlanInfo)]
         L.flex_gather_rows.argtypes = [vp, vp, vp, i64, i32, vp]
         L.flex_csv_load.argtypes = [C.c_char_p, C.POINTER(_HostCsr)]
+        L.flex_mtx_load.argtypes = [C.c_char_p, i32, C.POINTER(_HostCsr)]
+        L.flex_csv_save.argtypes = [C.c_char_p, C.POINTER(_Csr)]
+        L.flex_csr_save_bin.argtypes = [C.c_char_p, C.POINTER(_Csr)]
+        L.flex_csr_load_bin.argtypes = [C.c_char_p, C.POINTER(_HostCsr)]
         L.flex_host_csr_free.argtypes = [C.POINTER(_HostCsr)]
         L.flex_host_csr_free.restype = None
         L.flex_fill_dense_rand.argtypes = [vp, i64, i32]
@@ -169,6 +174,28 @@ def _take(s: _HostCsr) -> HostCsr:
 def csv_load(path: str) -> HostCsr:
     s = _HostCsr()
     _check(lib().flex_csv_load(os.fsencode(path), C.byref(s)), f"flex_csv_load({path})")
+    return _take(s)
+
+
+def mtx_load(path: str, sort_columns: bool = True) -> HostCsr:
+    s = _HostCsr()
+    _check(lib().flex_mtx_load(os.fsencode(path), int(sort_columns), C.byref(s)), f"flex_mtx_load({path})")
+    return _take(s)
+
+
+def csv_save(path: str, a: HostCsr):
+    v = a.view()
+    _check(lib().flex_csv_save(os.fsencode(path), C.byref(v)), f"flex_csv_save({path})")
+
+
+def csr_save_bin(path: str, a: HostCsr):
+    v = a.view()
+    _check(lib().flex_csr_save_bin(os.fsencode(path), C.byref(v)), f"flex_csr_save_bin({path})")
+
+
+def csr_load_bin(path: str) -> HostCsr:
+    s = _HostCsr()
+    _check(lib().flex_csr_load_bin(os.fsencode(path), C.byref(s)), f"flex_csr_load_bin({path})")
     return _take(s)
 
 

@@ -39,7 +39,17 @@ DataLoader::DataLoader(const std::string &data_path, const int di) : dl_original
     } else {
         const std::string data_name = data_path.substr(data_path.find_last_of("/") + 1);
         graph_name = data_name.substr(0, data_name.find("."));
-        FLEX_CHECK(flex_csv_load(data_path.c_str(), &h));  // amazon.csv draws its values from rand() here
+        const std::string ext = data_name.find('.') == std::string::npos ? "" : data_name.substr(data_name.find_last_of('.'));
+        if (ext == ".mtx")  // MatrixMarket directly (the reference converts first: data/SuiteSparse/mtx2csr.cc)
+            FLEX_CHECK(flex_mtx_load(data_path.c_str(), /*sort_columns=*/1, &h));
+        else if (ext == ".bin")  // binary CSR cache written by flex_csr_save_bin
+            FLEX_CHECK(flex_csr_load_bin(data_path.c_str(), &h));
+        else
+            FLEX_CHECK(flex_csv_load(data_path.c_str(), &h));  // amazon.csv draws its values from rand() here
+        if (h.m != h.n) {
+            flex_host_csr_free(&h);
+            throw std::runtime_error("DataLoader needs a square (graph) matrix");
+        }
     }
     rowPtr.assign(h.rowPtr, h.rowPtr + h.m + 1);
     col.assign(h.col, h.col + h.nnz);

@@ -7,6 +7,7 @@
 // the statistics come from a counting-sort transpose instead of the reference's
 // vector<map<int,float>> (tens of GB at Amazon scale).
 #include <algorithm>
+#include <cctype>
 #include <charconv>
 #include <cstdio>
 #include <cstdlib>
@@ -202,6 +203,186 @@ int flex_csv_load(const char *path, flex_host_csr *out) {
     const int rc = graph_statistics(out);
     if (rc) flex_host_csr_free(out);
     return rc;
+}
+
+// -------------------------------------------------------------------------------------------
+// MatrixMarket -> CSR, CSV writer, binary cache (data/SuiteSparse/mtx2csr.cc is the counterpart)
+
+static int finish_host_csr(flex_host_csr *out, int64_t m, int64_t n, std::vector<uint32_t> &rp,
+                           std::vector<uint32_t> &col, std::vector<float> &vals, const std::string &name) {
+    if (m >= INT32_MAX || n >= INT32_MAX || col.size() >= (size_t(1) << 32)) return FLEX_ERR_UNSUPPORTED;
+    out->m = static_cast<int32_t>(m);
+    out->n = static_cast<int32_t>(n);
+    out->nnz = static_cast<int64_t>(col.size());
+    out->rowPtr = static_cast<uint32_t *>(std::malloc((static_cast<size_t>(m) + 1) * sizeof(uint32_t)));
+    out->col = static_cast<uint32_t *>(std::malloc(std::max<size_t>(1, col.size()) * sizeof(uint32_t)));
+    out->vals = static_cast<float *>(std::malloc(std::max<size_t>(1, col.size()) * sizeof(float)));
+    if (!out->rowPtr || !out->col || !out->vals) {
+        flex_host_csr_free(out);
+        return FLEX_ERR_NOMEM;
+    }
+    std::copy(rp.begin(), rp.end(), out->rowPtr);
+    std::copy(col.begin(), col.end(), out->col);
+    std::copy(vals.begin(), vals.end(), out->vals);
+    out->uni_nb = 0;
+    for (int64_t r = 0; r < m; ++r) out->uni_nb += (rp[r + 1] - rp[r] == 1);
+    out->c = classes_by_name(name);
+    if (m != n) return FLEX_OK;  // the reference's statistics are defined for graphs (square) only
+    const int rc = graph_statistics(out);
+    // duplicate coordinates are legal in MatrixMarket files; they only make the statistics undefined
+    return rc == FLEX_ERR_DUPLICATE ? FLEX_OK : rc;
+}
+
+int flex_mtx_load(const char *path, int sort_columns, flex_host_csr *out) {
+    if (!path || !out) return FLEX_ERR_INVALID;
+    std::memset(out, 0, sizeof *out);
+    std::vector<char> buf;
+    if (!read_all(path, buf)) return FLEX_ERR_IO;
+    const char *p = buf.data(), *end = buf.data() + buf.size();
+    auto next_line = [&](Line &ln) {
+        if (p >= end) return false;
+        const char *q = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
+        if (!q) q = end;
+        ln.b = p;
+        ln.e = q;
+        p = q + 1;
+        return true;
+    };
+    Line ln;
+    if (!next_line(ln)) return FLEX_ERR_FORMAT;
+    std::string banner(ln.b, ln.e);
+    for (auto &ch : banner) ch = static_cast<char>(std::tolower(static_cast<unsigned char>(ch)));
+    if (banner.rfind("%%matrixmarket", 0) != 0 || banner.find("matrix") == std::string::npos ||
+        banner.find("coordinate") == std::string::npos)
+        return FLEX_ERR_FORMAT;  // mtx2csr.cc:72-79: only sparse coordinate matrices
+    const bool pattern = banner.find("pattern") != std::string::npos;
+    const bool cplx = banner.find("complex") != std::string::npos;
+    const bool symmetric = banner.find(" symmetric") != std::string::npos || banner.find("hermitian") != std::string::npos;
+    do {
+        if (!next_line(ln)) return FLEX_ERR_FORMAT;
+    } while (ln.b == ln.e || *ln.b == '%');
+    long long m = 0, n = 0, nz = 0;
+    {
+        std::string sz(ln.b, ln.e);
+        if (std::sscanf(sz.c_str(), "%lld %lld %lld", &m, &n, &nz) != 3 || m < 0 || n < 0 || nz < 0) return FLEX_ERR_FORMAT;
+    }
+    std::vector<uint32_t> ri(static_cast<size_t>(nz)), ci(static_cast<size_t>(nz));
+    std::vector<float> vv(static_cast<size_t>(nz));
+    for (long long i = 0; i < nz; ++i) {
+        do {
+            if (!next_line(ln)) return FLEX_ERR_FORMAT;
+        } while (ln.b == ln.e);
+        char *q = nullptr;
+        const long long r = std::strtoll(ln.b, &q, 10);
+        const char *q2 = q;
+        const long long c = std::strtoll(q2, &q, 10);
+        if (q == q2 || r < 1 || c < 1 || r > m || c > n) return FLEX_ERR_FORMAT;
+        double v = 1.0;  // pattern files carry no value (mtx2csr.cc:133-137)
+        if (!pattern) {
+            const char *q3 = q;
+            v = std::strtod(q3, &q);  // complex: the real part is kept, the imaginary one read and dropped
+            if (q == q3) return FLEX_ERR_FORMAT;
+            (void)cplx;
+        }
+        ri[i] = static_cast<uint32_t>(r - 1);
+        ci[i] = static_cast<uint32_t>(c - 1);
+        vv[i] = static_cast<float>(v);
+    }
+    // row counts, mirrored entries of symmetric files included (mtx2csr.cc:147-157)
+    std::vector<uint32_t> rp(static_cast<size_t>(m) + 1, 0u);
+    for (long long i = 0; i < nz; ++i) {
+        ++rp[ri[i] + 1];
+        if (symmetric && ri[i] != ci[i]) {
+            if (ci[i] >= static_cast<uint32_t>(m) || ri[i] >= static_cast<uint32_t>(n)) return FLEX_ERR_FORMAT;
+            ++rp[ci[i] + 1];
+        }
+    }
+    for (long long r = 0; r < m; ++r) rp[r + 1] += rp[r];
+    std::vector<uint32_t> col(rp[m]), cur(rp.begin(), rp.end() - 1);
+    std::vector<float> vals(rp[m]);
+    for (long long i = 0; i < nz; ++i) {  // file order inside each row, exactly as mtx2csr.cc:171-207
+        col[cur[ri[i]]] = ci[i];
+        vals[cur[ri[i]]++] = vv[i];
+        if (symmetric && ri[i] != ci[i]) {
+            col[cur[ci[i]]] = ri[i];
+            vals[cur[ci[i]]++] = vv[i];
+        }
+    }
+    if (sort_columns) {
+        std::vector<std::pair<uint32_t, float>> row;
+        for (long long r = 0; r < m; ++r) {
+            row.clear();
+            for (uint32_t e = rp[r]; e < rp[r + 1]; ++e) row.emplace_back(col[e], vals[e]);
+            std::stable_sort(row.begin(), row.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+            for (uint32_t e = rp[r], i = 0; e < rp[r + 1]; ++e, ++i) {
+                col[e] = row[i].first;
+                vals[e] = row[i].second;
+            }
+        }
+    }
+    std::string name(path);
+    if (auto s = name.find_last_of('/'); s != std::string::npos) name = name.substr(s + 1);
+    return finish_host_csr(out, m, n, rp, col, vals, name);
+}
+
+int flex_csv_save(const char *path, const flex_csr *A) {
+    if (!path) return FLEX_ERR_INVALID;
+    int rc = flex::validate_csr(A);
+    if (rc) return rc;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return FLEX_ERR_IO;
+    for (int32_t i = 0; i <= A->m; ++i) std::fprintf(f, i < A->m ? "%u," : "%u", A->rowPtr[i]);
+    std::fputc('\n', f);
+    for (int64_t i = 0; i < A->nnz; ++i) std::fprintf(f, i + 1 < A->nnz ? "%u," : "%u", A->col[i]);
+    std::fputc('\n', f);
+    for (int64_t i = 0; i < A->nnz; ++i) std::fprintf(f, i + 1 < A->nnz ? "%.9g," : "%.9g", static_cast<double>(A->vals[i]));
+    std::fputc('\n', f);
+    return std::fclose(f) == 0 ? FLEX_OK : FLEX_ERR_IO;
+}
+
+static const char kBinMagic[8] = {'F', 'L', 'E', 'X', 'C', 'S', 'R', '1'};
+
+int flex_csr_save_bin(const char *path, const flex_csr *A) {
+    if (!path) return FLEX_ERR_INVALID;
+    int rc = flex::validate_csr(A);
+    if (rc) return rc;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return FLEX_ERR_IO;
+    const int64_t hdr[3] = {A->m, A->n, A->nnz};
+    bool ok = std::fwrite(kBinMagic, 1, 8, f) == 8 && std::fwrite(hdr, sizeof(int64_t), 3, f) == 3 &&
+              std::fwrite(A->rowPtr, sizeof(uint32_t), static_cast<size_t>(A->m) + 1, f) == static_cast<size_t>(A->m) + 1 &&
+              std::fwrite(A->col, sizeof(uint32_t), static_cast<size_t>(A->nnz), f) == static_cast<size_t>(A->nnz) &&
+              std::fwrite(A->vals, sizeof(float), static_cast<size_t>(A->nnz), f) == static_cast<size_t>(A->nnz);
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? FLEX_OK : FLEX_ERR_IO;
+}
+
+int flex_csr_load_bin(const char *path, flex_host_csr *out) {
+    if (!path || !out) return FLEX_ERR_INVALID;
+    std::memset(out, 0, sizeof *out);
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return FLEX_ERR_IO;
+    char magic[8];
+    int64_t hdr[3];
+    if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, kBinMagic, 8) != 0 || std::fread(hdr, sizeof(int64_t), 3, f) != 3 ||
+        hdr[0] < 0 || hdr[1] < 0 || hdr[2] < 0 || hdr[0] >= INT32_MAX || hdr[1] >= INT32_MAX || hdr[2] >= (int64_t(1) << 32)) {
+        std::fclose(f);
+        return FLEX_ERR_FORMAT;
+    }
+    std::vector<uint32_t> rp(static_cast<size_t>(hdr[0]) + 1), col(static_cast<size_t>(hdr[2]));
+    std::vector<float> vals(static_cast<size_t>(hdr[2]));
+    const bool ok = std::fread(rp.data(), sizeof(uint32_t), rp.size(), f) == rp.size() &&
+                    std::fread(col.data(), sizeof(uint32_t), col.size(), f) == col.size() &&
+                    std::fread(vals.data(), sizeof(float), vals.size(), f) == vals.size();
+    std::fclose(f);
+    if (!ok || rp[0] != 0 || rp.back() != col.size()) return FLEX_ERR_FORMAT;
+    for (size_t r = 0; r + 1 < rp.size(); ++r)
+        if (rp[r] > rp[r + 1]) return FLEX_ERR_FORMAT;
+    for (uint32_t c : col)
+        if (c >= static_cast<uint32_t>(hdr[1])) return FLEX_ERR_FORMAT;
+    std::string name(path);
+    if (auto s = name.find_last_of('/'); s != std::string::npos) name = name.substr(s + 1);
+    return finish_host_csr(out, hdr[0], hdr[1], rp, col, vals, name);
 }
 
 int flex_fill_dense_rand(float *hostB, int64_t n, int k) {

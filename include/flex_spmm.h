@@ -136,6 +136,23 @@ typedef struct flex_host_csr {
 int flex_csv_load(const char *path, flex_host_csr *out);
 void flex_host_csr_free(flex_host_csr *a);
 
+/* ≙ data/SuiteSparse/mtx2csr.cc:57-247 (mmio_allinone): MatrixMarket coordinate file -> CSR.
+ * real / integer / pattern (value 1) / complex (real part); `symmetric` and `hermitian` files are
+ * expanded to both triangles.  sort_columns = 0 keeps the reference's layout (entries of a row in
+ * file order, which the reference's tilers mis-handle: mtx2csr.cc:171-195); 1 sorts each row by
+ * column.  m != n is allowed; graph statistics are filled only for square matrices. */
+int flex_mtx_load(const char *path, int sort_columns, flex_host_csr *out);
+
+/* ≙ writeCSR2csv (mtx2csr.cc:249-268): the 3-line CSV that DataLoader reads.  Values are written
+ * with 9 significant digits so that the file round-trips fp32 exactly (the reference's ofstream
+ * default keeps 6). */
+int flex_csv_save(const char *path, const flex_csr *A);
+
+/* Binary CSR cache (new; avoids re-parsing GB-sized CSVs): little-endian
+ * {magic "FLEXCSR1", int64 m, n, nnz} + rowPtr + col + vals. */
+int flex_csr_save_bin(const char *path, const flex_csr *A);
+int flex_csr_load_bin(const char *path, flex_host_csr *out);
+
 /* ≙ cpuX fill in DataLoader::cuda_alloc_cpy (DataLoader.cu:198-209), glibc rand() stream. */
 int flex_fill_dense_rand(float *hostB, int64_t n, int k);
 

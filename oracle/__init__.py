@@ -61,6 +61,10 @@ def lib():
         L.oracle_order_gorder.restype = C.c_int
         L.oracle_order_dfs.argtypes = [C.c_int64, u32p, u32p, u64p]
         L.oracle_order_dfs.restype = C.c_int
+        L.oracle_mtx_load.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                      C.POINTER(u32p), C.POINTER(u32p), C.POINTER(f32p)]
+        L.oracle_mtx_load.restype = C.c_int
+        L.oracle_free.argtypes = [C.c_void_p]
         L.oracle_perm_csr.argtypes = [C.c_int64, u32p, u32p, f32p, u64p, i32p, u32p, u32p, f32p]
         _lib = L
     return _lib
@@ -163,6 +167,23 @@ def order_dfs(rowPtr, col) -> np.ndarray:
     if rc:
         raise RuntimeError(f"oracle_order_dfs failed: {rc}")
     return rank[:n]
+
+
+def mtx_load(path: str):
+    """mtx2csr.cc's mmio_allinone: returns (m, n, rowPtr, col, vals) in the reference's unsorted layout."""
+    m, n, nnz = C.c_int64(), C.c_int64(), C.c_int64()
+    rp, col, val = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)(), C.POINTER(C.c_float)()
+    rc = lib().oracle_mtx_load(os.fsencode(path), C.byref(m), C.byref(n), C.byref(nnz), C.byref(rp), C.byref(col), C.byref(val))
+    if rc:
+        raise ValueError(f"oracle_mtx_load({path}) failed: {rc}")
+    try:
+        out = (m.value, n.value, np.ctypeslib.as_array(rp, shape=(m.value + 1,)).copy(),
+               np.ctypeslib.as_array(col, shape=(max(nnz.value, 1),))[: nnz.value].copy(),
+               np.ctypeslib.as_array(val, shape=(max(nnz.value, 1),))[: nnz.value].copy())
+    finally:
+        for p in (rp, col, val):
+            lib().oracle_free(C.cast(p, C.c_void_p))
+    return out
 
 
 def perm_csr(rowPtr, col, vals, rank):

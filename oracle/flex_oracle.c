@@ -6,6 +6,7 @@
  */
 #define _GNU_SOURCE
 #include "flex_oracle.h"
+#include <ctype.h>
 #include <errno.h>
 #include <float.h>
 #include <math.h>
@@ -700,3 +701,69 @@ int oracle_order_dfs(int64_t n, const uint32_t *rowPtr, const uint32_t *col, uin
     free(seen); free(stack_v); free(stack_e);
     return 0;
 }
+
+/* --------------------------------------------------------- MatrixMarket -> CSR */
+/* mmio_allinone, data/SuiteSparse/mtx2csr.cc:57-247: coordinate entries read with fscanf in file
+ * order ("%d %d %lg" real, "%d %d %lg %lg" complex keeping the real part, "%d %d %d" integer,
+ * "%d %d" pattern -> 1.0), 1-based -> 0-based, symmetric/hermitian files mirrored; rows filled
+ * in file order (columns NOT sorted).  Arrays are malloc'ed; free with free(). */
+int oracle_mtx_load(const char *path, int64_t *m_out, int64_t *n_out, int64_t *nnz_out,
+                    uint32_t **rowPtr_out, uint32_t **col_out, float **vals_out) {
+    FILE *f = fopen(path, "r");
+    if (!f) return -ENOENT;
+    char line[1100], banner[64], mtx[64], crd[64], dtype[64], storage[64];
+    if (!fgets(line, sizeof line, f) ||
+        sscanf(line, "%63s %63s %63s %63s %63s", banner, mtx, crd, dtype, storage) != 5) { fclose(f); return -EINVAL; }
+    for (char *p = mtx; *p; ++p) *p = (char)tolower(*p);
+    for (char *p = crd; *p; ++p) *p = (char)tolower(*p);
+    for (char *p = dtype; *p; ++p) *p = (char)tolower(*p);
+    for (char *p = storage; *p; ++p) *p = (char)tolower(*p);
+    if (strcmp(banner, "%%MatrixMarket") || strcmp(mtx, "matrix") || strcmp(crd, "coordinate")) { fclose(f); return -EINVAL; }
+    const int isPattern = !strcmp(dtype, "pattern"), isReal = !strcmp(dtype, "real"),
+              isComplex = !strcmp(dtype, "complex"), isInteger = !strcmp(dtype, "integer");
+    const int isSym = !strcmp(storage, "symmetric") || !strcmp(storage, "hermitian");
+    if (!(isPattern || isReal || isComplex || isInteger)) { fclose(f); return -EINVAL; }
+    do {
+        if (!fgets(line, sizeof line, f)) { fclose(f); return -EINVAL; }
+    } while (line[0] == '%');
+    int m, n, nz;
+    if (sscanf(line, "%d %d %d", &m, &n, &nz) != 3) { fclose(f); return -EINVAL; }
+    int *cnt = (int *)calloc((size_t)m + 1, sizeof(int));
+    int *ri = (int *)malloc(sizeof(int) * (size_t)(nz ? nz : 1)), *ci = (int *)malloc(sizeof(int) * (size_t)(nz ? nz : 1));
+    float *vv = (float *)malloc(sizeof(float) * (size_t)(nz ? nz : 1));
+    for (int i = 0; i < nz; ++i) {
+        int a, b, iv, got;
+        double fv = 0, fim;
+        if (isReal) got = fscanf(f, "%d %d %lg\n", &a, &b, &fv) == 3;
+        else if (isComplex) got = fscanf(f, "%d %d %lg %lg\n", &a, &b, &fv, &fim) == 4;
+        else if (isInteger) { got = fscanf(f, "%d %d %d\n", &a, &b, &iv) == 3; fv = iv; }
+        else { got = fscanf(f, "%d %d\n", &a, &b) == 2; fv = 1.0; }
+        if (!got) { fclose(f); free(cnt); free(ri); free(ci); free(vv); return -EINVAL; }
+        a--; b--;
+        cnt[a]++;
+        ri[i] = a; ci[i] = b; vv[i] = (float)fv;
+    }
+    fclose(f);
+    if (isSym)
+        for (int i = 0; i < nz; ++i)
+            if (ri[i] != ci[i]) cnt[ci[i]]++;
+    uint32_t *rp = (uint32_t *)calloc((size_t)m + 1, sizeof(uint32_t));
+    for (int r = 0; r < m; ++r) rp[r + 1] = rp[r] + (uint32_t)cnt[r];
+    const uint32_t total = rp[m];
+    uint32_t *col = (uint32_t *)malloc(sizeof(uint32_t) * (total ? total : 1));
+    float *vals = (float *)malloc(sizeof(float) * (total ? total : 1));
+    memset(cnt, 0, sizeof(int) * ((size_t)m + 1));
+    for (int i = 0; i < nz; ++i) {
+        uint32_t o = rp[ri[i]] + (uint32_t)cnt[ri[i]]++;
+        col[o] = (uint32_t)ci[i]; vals[o] = vv[i];
+        if (isSym && ri[i] != ci[i]) {
+            o = rp[ci[i]] + (uint32_t)cnt[ci[i]]++;
+            col[o] = (uint32_t)ri[i]; vals[o] = vv[i];
+        }
+    }
+    free(cnt); free(ri); free(ci); free(vv);
+    *m_out = m; *n_out = n; *nnz_out = total;
+    *rowPtr_out = rp; *col_out = col; *vals_out = vals;
+    return 0;
+}
+void oracle_free(void *p) { free(p); }

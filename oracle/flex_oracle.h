@@ -76,6 +76,12 @@ int oracle_order_rcm(int64_t n, const uint32_t *rowPtr, const uint32_t *col, uin
  * (DataLoader.cu:808). */
 int oracle_order_gorder(int64_t n, const uint32_t *rowPtr, const uint32_t *col, uint64_t window, uint64_t *rank);
 
+/* mmio_allinone, data/SuiteSparse/mtx2csr.cc:57-247: MatrixMarket coordinate file -> CSR in the
+ * reference's (file-order, unsorted) layout.  Arrays are malloc'ed: release with oracle_free. */
+int oracle_mtx_load(const char *path, int64_t *m, int64_t *n, int64_t *nnz, uint32_t **rowPtr, uint32_t **col,
+                    float **vals);
+void oracle_free(void *p);
+
 /* DataLoaderDFS ordering, DataLoader.cu:324-395: depth-first discovery order from vertex 0. */
 int oracle_order_dfs(int64_t n, const uint32_t *rowPtr, const uint32_t *col, uint64_t *rank);
 

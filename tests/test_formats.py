@@ -1,0 +1,102 @@
+"""On-disk formats either side of the hot path: MatrixMarket -> CSR (mtx2csr.cc), CSV writer, binary cache."""
+import os
+
+import numpy as np
+import pytest
+import scipy.io
+import scipy.sparse as sp
+
+import flex_amd
+import oracle
+from conftest import GOLDEN
+
+MTX = {
+    "general_real": """%%MatrixMarket matrix coordinate real general
+% a comment
+%
+4 5 6
+1 1 1.5
+3 2 -2.25
+1 4 3.0e-1
+4 5 7
+2 3 0.125
+1 2 9
+""",
+    "symmetric_real": """%%MatrixMarket matrix coordinate real symmetric
+4 4 5
+1 1 2.0
+3 1 -1.0
+4 2 0.5
+4 4 4.0
+2 1 3.5
+""",
+    "pattern_general": """%%MatrixMarket matrix coordinate pattern general
+3 3 4
+2 1
+1 3
+3 3
+3 1
+""",
+    "integer_symmetric": """%%MatrixMarket matrix coordinate integer symmetric
+3 3 3
+2 1 -1
+3 3 1
+3 2 1
+""",
+}
+
+
+@pytest.mark.parametrize("name", sorted(MTX))
+def test_mtx_matches_oracle_layout_and_scipy(tmp_path, name):
+    path = tmp_path / f"{name}.mtx"
+    path.write_text(MTX[name])
+    m, n, rp, col, val = oracle.mtx_load(str(path))                  # mtx2csr.cc's unsorted layout
+    a = flex_amd.mtx_load(str(path), sort_columns=False)
+    assert (a.m, a.n) == (m, n)
+    assert np.array_equal(a.rowPtr, rp) and np.array_equal(a.col, col) and np.array_equal(a.vals, val)
+    s = flex_amd.mtx_load(str(path), sort_columns=True)
+    ref = sp.csr_matrix(scipy.io.mmread(str(path)))                  # independent reader
+    ref.sort_indices()
+    assert np.array_equal(s.rowPtr, ref.indptr) and np.array_equal(s.col, ref.indices)
+    assert np.array_equal(s.vals, ref.data.astype(np.float32))
+
+
+def test_mtx_errors(tmp_path):
+    bad = tmp_path / "bad.mtx"
+    bad.write_text("%%MatrixMarket matrix array real general\n2 2\n1\n2\n3\n4\n")
+    with pytest.raises(flex_amd.FlexError, match="does not parse"):
+        flex_amd.mtx_load(str(bad))
+    oob = tmp_path / "oob.mtx"
+    oob.write_text("%%MatrixMarket matrix coordinate real general\n2 2 1\n3 1 1.0\n")
+    with pytest.raises(flex_amd.FlexError):
+        flex_amd.mtx_load(str(oob))
+    with pytest.raises(flex_amd.FlexError, match="could not be read"):
+        flex_amd.mtx_load(str(tmp_path / "missing.mtx"))
+
+
+def test_mtx_to_csv_is_what_dataloader_reads(tmp_path):
+    """prepare_mtx_data.sh: mtx -> conv -> csv -> DataLoader.  Same pipeline, exact fp32 round trip."""
+    path = tmp_path / "g.mtx"
+    path.write_text(MTX["symmetric_real"])
+    a = flex_amd.mtx_load(str(path))
+    flex_amd.csv_save(str(tmp_path / "g.csv"), a)
+    b = flex_amd.csv_load(str(tmp_path / "g.csv"))
+    o = oracle.csv_load(str(tmp_path / "g.csv"))
+    for x in (b, o):
+        assert np.array_equal(x.rowPtr, a.rowPtr) and np.array_equal(x.col, a.col) and np.array_equal(x.vals, a.vals)
+    assert not b.is_directed and b.n_edges_asymmetric == 0
+
+
+def test_csv_and_binary_round_trip_pubmed(tmp_path):
+    a = flex_amd.csv_load(os.path.join(GOLDEN, "pubmed.csv"))
+    flex_amd.csv_save(str(tmp_path / "p.csv"), a)
+    flex_amd.csr_save_bin(str(tmp_path / "p.bin"), a)
+    b = flex_amd.csv_load(str(tmp_path / "p.csv"))
+    c = flex_amd.csr_load_bin(str(tmp_path / "p.bin"))
+    for x in (b, c):
+        assert np.array_equal(x.rowPtr, a.rowPtr) and np.array_equal(x.col, a.col) and np.array_equal(x.vals, a.vals)
+        assert (x.n_edges_one_way, x.is_directed, x.uni_nb) == (a.n_edges_one_way, a.is_directed, a.uni_nb)
+    with open(tmp_path / "junk.bin", "wb") as f:
+        f.write(b"not a csr file at all")
+    with pytest.raises(flex_amd.FlexError, match="does not parse"):
+        flex_amd.csr_load_bin(str(tmp_path / "junk.bin"))
