@@ -7,6 +7,7 @@
 #include <cstring>
 #include <memory>
 
+#include "../../../include/flex_mg.h"
 #include "../../../include/flex_vendor.h"
 #include "flex.h"
 
@@ -180,6 +181,33 @@ void run(DataLoader &input_vo) {
                         input_vo.graph_name.c_str(), input_vo.n, input_vo.nnz, input_vo.dim, r.ord.c_str(),
                         r.sched.c_str(), r.t_us, r.gflops, r.balg_gbs, r.max_err, r.errs, perfRes.cuSpmmProcessing);
     }
+    int mg_errs = 0;
+    if (o.gpus > 0) {  // row-sharded over several GPUs (new; the reference is single-GPU, flex.cu:4137)
+        flex_mg *mg = nullptr;
+        const flex_csr a = input_vo.csr_view();
+        FLEX_CHECK(flex_mg_create(&mg, &a, static_cast<int>(input_vo.dim), o.gpus, nullptr, FLEX_ORDER_CLUSTER));
+        double bcast_ms = 0, us = 0;
+        FLEX_CHECK(flex_mg_set_B(mg, input_vo.cpuX.data(), &bcast_ms));
+        FLEX_CHECK(flex_mg_time(mg, o.warmup, o.iters, &us));
+        FLEX_CHECK(flex_mg_get_C(mg, h_res.get()));
+        std::vector<int64_t> bounds(o.gpus + 1), snnz(o.gpus);
+        flex_mg_shard_info(mg, bounds.data(), snnz.data());
+        flex_mg_destroy(mg);
+        double max_err = 0;
+        if (!input_vo.h_ref_c.empty()) {
+            Mat probe(input_vo, 0, 0);
+            mg_errs = resCheck(input_vo.h_ref_c.data(), h_res.get(), probe, perfRes, &max_err);
+        }
+        std::printf("MG x%d cluster  t/us %.1f  GFLOP/s %.1f  B bcast/ms %.3f  errs %d  shard nnz:", o.gpus, us,
+                    flops / us * 1e-3, bcast_ms, mg_errs);
+        for (int i = 0; i < o.gpus; ++i) std::printf(" %lld", static_cast<long long>(snnz[i]));
+        std::printf("\n");
+        if (o.json)
+            std::printf("{\"graph\":\"%s\",\"k\":%zu,\"ord\":\"MG\",\"schedule\":\"cluster\",\"gpus\":%d,\"t_us\":%.3f,\"gflops\":%.2f,"
+                        "\"b_bcast_ms\":%.3f,\"errs\":%d}\n",
+                        input_vo.graph_name.c_str(), input_vo.dim, o.gpus, us, flops / us * 1e-3, bcast_ms, mg_errs);
+    }
     for (const Row &r : rows)
         if (r.errs > 0) throw std::runtime_error("resCheck failed");  // ≙ assert(!count), flex.cu:4205
+    if (mg_errs > 0) throw std::runtime_error("resCheck failed (multi-GPU)");
 }

@@ -360,3 +360,16 @@ def test_b_larger_than_4GiB_uses_64bit_row_addressing():
     gold = oracle.spmm(a.rowPtr, remap, a.vals, Bh_rows, nthreads=8)
     cnt, max_err, _, _ = oracle.rescheck(gold, C.cpu().numpy(), a.rowPtr)
     assert cnt == 0, (cnt, max_err)
+
+
+def test_cxx_multi_gpu_driver_on_one_device():
+    """libflex_mg.so (single-process row sharding + RCCL broadcast) with one device: plumbing and parity."""
+    import json
+    import subprocess
+    exe = os.path.join(os.path.dirname(flex_amd.lib_path()), "flex")
+    out = subprocess.run([exe, os.path.join(GOLDEN, "pubmed.csv"), "32", "--json", "--gpus", "1"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = [json.loads(line) for line in out.stdout.splitlines() if line.startswith("{")]
+    mg = [r for r in rows if r["ord"] == "MG"]
+    assert len(mg) == 1 and mg[0]["errs"] == 0 and mg[0]["gpus"] == 1
