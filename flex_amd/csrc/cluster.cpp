@@ -69,7 +69,6 @@ struct Clusterer {
             raw[u] = 0;
         }
         for (const auto &vw : adj[u]) add(vw.first, vw.second);
-        std::sort(touched.begin(), touched.end());  // deterministic tie-breaking
         auto &list = adj[u];
         list.clear();
         list.reserve(touched.size());
@@ -81,7 +80,8 @@ struct Clusterer {
             acc[r] = 0.f;
             list.emplace_back(r, w);
             const double gain = static_cast<double>(w) - cdeg[r] * du_over_M;  // ~ delta modularity * M
-            if (gain > best_gain) {
+            // ties go to the smaller community id, whatever order the neighbours were met in
+            if (gain > best_gain || (gain == best_gain && gain > 0.0 && r < best)) {
                 best_gain = gain;
                 best = r;
             }
