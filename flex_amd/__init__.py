@@ -11,6 +11,7 @@ from .binding import (  # noqa: F401
     FLEX_ORDER_RCM,
     FLEX_ORDER_CLUSTER,
     FLEX_ORDER_GORDER,
+    FLEX_PLAN_STATS,
     FlexError,
     HostCsr,
     Plan,

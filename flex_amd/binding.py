@@ -21,6 +21,7 @@ FLEX_ORDER_NATURAL = 0
 FLEX_ORDER_RCM = 1
 FLEX_ORDER_CLUSTER = 2
 FLEX_ORDER_GORDER = 3
+FLEX_PLAN_STATS = 0x100
 
 
 class FlexError(RuntimeError):
@@ -47,7 +48,16 @@ class _PlanInfo(C.Structure):  # flex_plan_info
                 ("nnz", C.c_int64), ("n_tasks", C.c_int64), ("n_chunks", C.c_int64),
                 ("n_split_rows", C.c_int64), ("n_partials", C.c_int64),
                 ("device_bytes", C.c_int64), ("lanes_per_nz", C.c_int32), ("order", C.c_int32),
-                ("plan_ms", C.c_double)]
+                ("plan_ms", C.c_double), ("n_slots", C.c_int64)]
+
+
+class _PlanStats(C.Structure):  # flex_plan_stats
+    _fields_ = [("records", C.c_int64), ("cols_wave", C.c_int64), ("cols_wg", C.c_int64),
+                ("cols_xcd", C.c_int64), ("reuse_wave", C.c_double), ("reuse_wg", C.c_double),
+                ("reuse_xcd", C.c_double), ("gather_bytes", C.c_double), ("l2_bytes", C.c_double),
+                ("chunk_rec_max", C.c_int64), ("chunk_rec_mean", C.c_double),
+                ("chunk_imb_pct", C.c_double), ("xcd_imb_pct", C.c_double),
+                ("split_nnz_pct", C.c_double), ("pad_pct", C.c_double), ("n_workgroups", C.c_int64)]
 
 
 class _SynthParams(C.Structure):  # flex_synth_params
@@ -60,7 +70,7 @@ class _SynthParams(C.Structure):  # flex_synth_params
 # every symbol include/flex_spmm.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = [
     "flex_plan_create", "flex_plan_create_mapped", "flex_plan_create_rows", "flex_spmm",
-    "flex_plan_destroy", "flex_plan_get_info", "flex_gather_rows", "flex_csv_load", "flex_mtx_load",
+    "flex_plan_destroy", "flex_plan_get_info", "flex_plan_get_stats", "flex_gather_rows", "flex_csv_load", "flex_mtx_load",
     "flex_csv_save", "flex_csr_save_bin", "flex_csr_load_bin",
     "flex_host_csr_free", "flex_fill_dense_rand", "flex_order_rcm", "flex_order_cluster", "flex_order_gorder", "flex_perm_csr",
     "flex_order_deg", "flex_order_dfs", "flex_shard_rows", "flex_synth_graph", "flex_synth_preset", "flex_strerror", "flex_last_hip_error",
@@ -104,6 +114,7 @@ def lib():
         L.flex_spmm.argtypes = [vp, vp, vp, vp]
         L.flex_plan_destroy.argtypes = [vp]
         L.flex_plan_get_info.argtypes = [vp, C.POINTER(_PlanInfo)]
+        L.flex_plan_get_stats.argtypes = [vp, C.POINTER(_PlanStats)]
         L.flex_gather_rows.argtypes = [vp, vp, vp, i64, i32, vp]
         L.flex_csv_load.argtypes = [C.c_char_p, C.POINTER(_HostCsr)]
         L.flex_mtx_load.argtypes = [C.c_char_p, i32, C.POINTER(_HostCsr)]
@@ -310,6 +321,12 @@ class Plan:
         i = _PlanInfo()
         _check(lib().flex_plan_get_info(self._h, C.byref(i)), "flex_plan_get_info")
         return {f: getattr(i, f) for f, _ in _PlanInfo._fields_}
+
+    def stats(self) -> dict:
+        """flex_plan_stats (≙ alpha_stats_collect + B-Re1/B-Re2); the plan must be made with FLEX_PLAN_STATS."""
+        st = _PlanStats()
+        _check(lib().flex_plan_get_stats(self._h, C.byref(st)), "flex_plan_get_stats")
+        return {f: getattr(st, f) for f, _ in _PlanStats._fields_}
 
     def spmm(self, dB_ptr: int, dC_ptr: int, stream: int = 0):
         _check(lib().flex_spmm(self._h, dB_ptr, dC_ptr, stream), "flex_spmm")

@@ -13,7 +13,7 @@ void Mat::csr2_DiagTiling() {
     // a reordered loader hands its vo_mp so that B stays un-permuted and C comes back in the
     // original row order (the reference needs permuteX + segVoMap for that)
     const int32_t *vo = dl.vertex_order_abbr == "OVO" ? nullptr : dl.vo_mp.data();
-    FLEX_CHECK(flex_plan_create_mapped(&plan, &a, vo, k, device, schedule));
+    FLEX_CHECK(flex_plan_create_mapped(&plan, &a, vo, k, device, schedule | FLEX_PLAN_STATS));
 }
 
 void Mat::launch_prep() {
@@ -33,4 +33,23 @@ flex_plan_info Mat::info() const {
     flex_plan_info i{};
     if (plan) flex_plan_get_info(plan, &i);
     return i;
+}
+
+
+flex_plan_stats Mat::stats() const {
+    flex_plan_stats s{};
+    if (plan) flex_plan_get_stats(plan, &s);
+    return s;
+}
+
+void Mat::alpha_stats_collect(FILE *stream) const {
+    const flex_plan_info i = info();
+    const flex_plan_stats s = stats();
+    std::fprintf(stream, " %lld chunks in %lld workgroups, %.0f%% chunk imb (max %lld, mean %.1f records); XCD slices %.1f%% imb.\n",
+                 static_cast<long long>(i.n_chunks), static_cast<long long>(s.n_workgroups), s.chunk_imb_pct,
+                 static_cast<long long>(s.chunk_rec_max), s.chunk_rec_mean, s.xcd_imb_pct);
+    std::fprintf(stream, " Work %.1f%% in %lld split rows (%lld pieces), %.1f%% padding.\n", s.split_nnz_pct,
+                 static_cast<long long>(i.n_split_rows), static_cast<long long>(i.n_partials), s.pad_pct);
+    std::fprintf(stream, " B reuse: wave %.2f, workgroup %.2f, XCD %.2f; gather model %.1f MB, L2 model %.1f MB.\n",
+                 s.reuse_wave, s.reuse_wg, s.reuse_xcd, s.gather_bytes * 1e-6, s.l2_bytes * 1e-6);
 }

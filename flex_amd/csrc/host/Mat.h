@@ -28,4 +28,6 @@ class Mat {
     void alpha_freeMatGPU();   // ≙ mat.cuh:184-193
     int row_nnz_get(int r) const { return static_cast<int>(rowPtr[r + 1] - rowPtr[r]); }
     flex_plan_info info() const;
+    flex_plan_stats stats() const;
+    void alpha_stats_collect(FILE *stream) const;  // ≙ mat.cu:944-1065: imbalance / reuse summary of the plan
 };

@@ -7,6 +7,7 @@ struct RunOptions {
     int warmup = 5, iters = 10;  // the reference's vendor protocol, flex.cu:5766-5789
     bool json = false;           // one JSON line per configuration instead of the table only
     bool vendor = true;          // run hipSPARSE as gold + baseline (false: CPU-free self check only)
+    bool stats = false;          // print each plan's imbalance / reuse summary (≙ alpha_stats_collect)
     int gpus = 0;                // > 0: also run the row-sharded multi-GPU path on that many devices (flex_mg.h)
 };
 RunOptions &run_options();

@@ -92,6 +92,7 @@ struct Row {
     double t_us, gflops, balg_gbs, plan_ms, max_err;
     int errs;
     flex_plan_info info;
+    flex_plan_stats stats;
 };
 
 void bench_one(DataLoader &dl, unsigned schedule, const char *sched_name, const DataLoader &gold_src, float *h_res,
@@ -102,6 +103,10 @@ void bench_one(DataLoader &dl, unsigned schedule, const char *sched_name, const 
     mat.csr2_DiagTiling();
     mat.alpha_transfer();
     mat.launch_prep();
+    if (o.stats) {
+        std::printf("%s/%s:\n", dl.vertex_order_abbr.c_str(), sched_name);
+        mat.alpha_stats_collect(stdout);
+    }
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));
     HIP_CHECK(hipEventCreate(&e1));
@@ -122,7 +127,7 @@ void bench_one(DataLoader &dl, unsigned schedule, const char *sched_name, const 
     const double flops = 2.0 * dl.nnz * dl.dim;
     const double balg = (double(dl.n) + 1 + 2.0 * dl.nnz + 2.0 * dl.n * dl.dim) * 4;  // flex.cu:4672, 5795
     rows.push_back({dl.vertex_order_abbr, sched_name, t_us, flops / t_us * 1e-3, balg / t_us * 1e-3,
-                    mat.info().plan_ms, max_err, errs, mat.info()});
+                    mat.info().plan_ms, max_err, errs, mat.info(), mat.stats()});
     perfRes.flex_spmm_time.push_back(static_cast<float>(t_us * 1e-3));
     mat.alpha_freeMatGPU();
 }
@@ -169,17 +174,22 @@ void run(DataLoader &input_vo) {
     if (o.vendor)
         std::printf("hipSPARSE setup/us: %.2f , processing/us: %.2f  (%.1f GFLOP/s)\n", perfRes.cuSpmmSetup,
                     perfRes.cuSpmmProcessing, flops / perfRes.cuSpmmProcessing * 1e-3);
-    std::printf("%-4s %-8s %10s %10s %10s %8s %8s %8s %8s %9s\n", "Ord", "sched", "t/us", "GFLOP/s", "Balg GB/s",
-                "%8TB/s", "chunks", "split", "plan/ms", "errs");
+    // B-Re1 / B-Re2 as in the reference's table (flex.cu:5217-5223): nnz per distinct B row inside one
+    // unit of work (here a chunk = one wave) and inside one cache domain (here an XCD's L2)
+    std::printf("%-4s %-8s %10s %10s %10s %8s %8s %8s %7s %7s %8s %9s\n", "Ord", "sched", "t/us", "GFLOP/s", "Balg GB/s",
+                "%8TB/s", "chunks", "split", "B-Re1", "B-Re2", "plan/ms", "errs");
     for (const Row &r : rows) {
-        std::printf("%-4s %-8s %10.1f %10.1f %10.1f %8.2f %8lld %8lld %8.1f %9d\n", r.ord.c_str(), r.sched.c_str(),
-                    r.t_us, r.gflops, r.balg_gbs, r.balg_gbs / 8000.0 * 100, static_cast<long long>(r.info.n_chunks),
-                    static_cast<long long>(r.info.n_split_rows), r.plan_ms, r.errs);
+        std::printf("%-4s %-8s %10.1f %10.1f %10.1f %8.2f %8lld %8lld %7.2f %7.2f %8.1f %9d\n", r.ord.c_str(),
+                    r.sched.c_str(), r.t_us, r.gflops, r.balg_gbs, r.balg_gbs / 8000.0 * 100,
+                    static_cast<long long>(r.info.n_chunks), static_cast<long long>(r.info.n_split_rows),
+                    r.stats.reuse_wave, r.stats.reuse_xcd, r.plan_ms, r.errs);
         if (o.json)
             std::printf("{\"graph\":\"%s\",\"n\":%zu,\"nnz\":%zu,\"k\":%zu,\"ord\":\"%s\",\"schedule\":\"%s\",\"t_us\":%.3f,"
-                        "\"gflops\":%.2f,\"balg_gbs\":%.2f,\"max_err\":%.3g,\"errs\":%d,\"vendor_us\":%.3f}\n",
+                        "\"gflops\":%.2f,\"balg_gbs\":%.2f,\"max_err\":%.3g,\"errs\":%d,\"vendor_us\":%.3f,\"b_re1\":%.3f,\"b_re2\":%.3f,"
+                        "\"chunk_imb_pct\":%.1f,\"xcd_imb_pct\":%.2f}\n",
                         input_vo.graph_name.c_str(), input_vo.n, input_vo.nnz, input_vo.dim, r.ord.c_str(),
-                        r.sched.c_str(), r.t_us, r.gflops, r.balg_gbs, r.max_err, r.errs, perfRes.cuSpmmProcessing);
+                        r.sched.c_str(), r.t_us, r.gflops, r.balg_gbs, r.max_err, r.errs, perfRes.cuSpmmProcessing,
+                        r.stats.reuse_wave, r.stats.reuse_xcd, r.stats.chunk_imb_pct, r.stats.xcd_imb_pct);
     }
     int mg_errs = 0;
     if (o.gpus > 0) {  // row-sharded over several GPUs (new; the reference is single-GPU, flex.cu:4137)

@@ -66,9 +66,11 @@ struct flex_plan {
     uint32_t *d_piece_row = nullptr, *d_split_cnt = nullptr;
     uint32_t partial_bytes = 0;
     bool fused_fixup = false;
-    uint32_t n_tasks = 0, n_chunks = 0, n_split = 0, n_partials = 0;
+    uint32_t n_tasks = 0, n_chunks = 0, n_slots = 0, n_split = 0, n_partials = 0;  // n_slots: chunk table incl. padding
     int64_t device_bytes = 0;
     double plan_ms = 0;
+    bool has_stats = false;
+    flex_plan_stats stats{};
 };
 
 namespace {
@@ -92,6 +94,50 @@ void free_plan_device(flex_plan *p) {
     (void)hipFree(p->d_split);
     (void)hipFree(p->d_piece_row);
     (void)hipFree(p->d_split_cnt);
+}
+
+// ≙ alpha_stats_collect (mat.cu:944-1065): distinct B rows per chunk / workgroup / XCD slice by
+// stamping, and how evenly records are cut.  Padding records repeat the row's last column, so they
+// change no distinct count.
+void collect_stats(flex_plan *p, const std::vector<uint2> &rec, const std::vector<uint4> &chunk, int64_t split_nnz) {
+    flex_plan_stats &st = p->stats;
+    st = flex_plan_stats{};
+    const uint32_t n_chunks = static_cast<uint32_t>(chunk.size());
+    uint32_t nblk = (n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    nblk = (nblk + kXcds - 1) / kXcds * kXcds;  // as launch_spmm cuts the grid
+    const uint32_t cpx = std::max(1u, nblk / kXcds);
+    const uint32_t row_bytes32 = static_cast<uint32_t>(p->k) * 4u;
+    std::vector<uint32_t> seen_wave(p->n, 0u), seen_wg(p->n, 0u), seen_xcd(p->n, 0u);
+    int64_t xcd_rec[kXcds] = {0};
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        const uint32_t wg = c / kWavesPerBlock;
+        const uint32_t xcd = p->xcd_remap ? std::min<uint32_t>(wg / cpx, kXcds - 1) : wg % kXcds;
+        const uint32_t n_rec = chunk[c].w - chunk[c].z;
+        if (chunk[c].y == 0) continue;  // padding slot
+        for (uint32_t z = chunk[c].z; z < chunk[c].w; ++z) {
+            const uint32_t col = p->off32 ? rec[z].x / row_bytes32 : rec[z].x;
+            if (seen_wave[col] != c + 1) seen_wave[col] = c + 1, st.cols_wave++;
+            if (seen_wg[col] != wg + 1) seen_wg[col] = wg + 1, st.cols_wg++;
+            if (seen_xcd[col] != xcd + 1) seen_xcd[col] = xcd + 1, st.cols_xcd++;
+        }
+        xcd_rec[xcd] += n_rec;
+        st.chunk_rec_max = std::max<int64_t>(st.chunk_rec_max, n_rec);
+    }
+    st.records = static_cast<int64_t>(rec.size());
+    st.n_workgroups = nblk;
+    const double nnz = static_cast<double>(p->nnz);
+    st.reuse_wave = st.cols_wave ? nnz / st.cols_wave : 0.0;
+    st.reuse_wg = st.cols_wg ? nnz / st.cols_wg : 0.0;
+    st.reuse_xcd = st.cols_xcd ? nnz / st.cols_xcd : 0.0;
+    st.gather_bytes = 4.0 * (p->m + 1) + 8.0 * nnz + 4.0 * nnz * p->k + 4.0 * p->m * p->k;
+    st.l2_bytes = 4.0 * (p->m + 1) + 8.0 * st.records + 4.0 * p->k * st.cols_xcd + 4.0 * p->m * p->k;
+    st.chunk_rec_mean = p->n_chunks ? static_cast<double>(st.records) / p->n_chunks : 0.0;
+    st.chunk_imb_pct = st.chunk_rec_mean > 0 ? 100.0 * st.chunk_rec_max / st.chunk_rec_mean - 100.0 : 0.0;
+    const int64_t xmax = *std::max_element(xcd_rec, xcd_rec + kXcds);
+    st.xcd_imb_pct = st.records ? 100.0 * xmax * kXcds / st.records - 100.0 : 0.0;
+    st.split_nnz_pct = nnz > 0 ? 100.0 * split_nnz / nnz : 0.0;
+    st.pad_pct = nnz > 0 ? 100.0 * (st.records - nnz) / nnz : 0.0;
+    p->has_stats = true;
 }
 
 // Rows [r0,r1) of A.  col_map: B row read by column c (NULL = c).  dst_map: C row
@@ -149,6 +195,7 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     }
     uint32_t n_partials = 0;
     uint32_t wave_cost = 0;
+    int64_t split_nnz = 0;
     const uint32_t row_bytes32 = static_cast<uint32_t>(k) * 4u;
     auto emit_records = [&](uint32_t e0, uint32_t e1) {
         for (uint32_t e = e0; e < e1; ++e) {
@@ -186,6 +233,7 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
                 const uint32_t nchunk = (len + piece - 1) / piece;
                 const uint32_t per = ((len + nchunk - 1) / nchunk + S - 1) / S * S;  // whole steps
                 split.push_back({dst, n_partials, 0});
+                split_nnz += len;
                 for (uint32_t c0 = e0; c0 < e1; c0 += per) {
                     const uint32_t c1 = std::min(e1, c0 + per);
                     w_task.push_back(static_cast<uint32_t>(t_dst.size()));  // a piece is a chunk of its own
@@ -220,13 +268,54 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     if ((rc = upload(&p->d_rec, rec, &p->device_bytes))) return rc;
     if ((rc = upload(&p->d_t_beg, t_beg, &p->device_bytes))) return rc;
     if ((rc = upload(&p->d_t_dst, t_dst, &p->device_bytes))) return rc;
-    // Chunk table in launch order: the kernel gives XCD x the x-th eighth of it.
-    const uint32_t n_all = static_cast<uint32_t>(w_task.size() - 1);
-    std::vector<uint4> chunk(n_all);
-    for (uint32_t c = 0; c < n_all; ++c)
-        chunk[c] = make_uint4(w_task[c], w_task[c + 1] - w_task[c], t_beg[w_task[c]], t_beg[w_task[c + 1]]);
-    p->n_chunks = static_cast<uint32_t>(chunk.size());
+    // Chunk table in launch order: the kernel gives XCD x the x-th eighth of it.  The eighths are cut
+    // by COST (records + per-row and per-chunk overhead), not by chunk count, and padded with empty
+    // chunks to a common length: schedules that put the heavy rows at one end (degree order, RCM,
+    // Gorder) otherwise leave one XCD with up to 1.9x the mean work (flickr shape).
+    const uint32_t n_real = static_cast<uint32_t>(w_task.size() - 1);
+    auto header = [&](uint32_t c) {
+        return make_uint4(w_task[c], w_task[c + 1] - w_task[c], t_beg[w_task[c]], t_beg[w_task[c + 1]]);
+    };
+    std::vector<uint4> chunk;
+    if (p->xcd_remap && n_real >= 8u * kXcds * kWavesPerBlock && env_long("FLEX_XCD_BALANCE", 1) != 2) {
+        // cost of a chunk in units of one 512-byte gather (a record at k = 128): measured per-XCD times
+        // on the flickr shape fit  t = a * records + ~20 a * chunks  with rows nearly free
+        const uint64_t chunk_cost = static_cast<uint64_t>(env_long("FLEX_CHUNK_COST", 16)) * 32u;
+        const uint64_t task_cost = static_cast<uint64_t>(env_long("FLEX_TASK_COST", 2)) * 32u;
+        std::vector<uint64_t> cum(n_real + 1, 0);
+        for (uint32_t c = 0; c < n_real; ++c) {
+            const uint4 h = header(c);
+            cum[c + 1] = cum[c] + static_cast<uint64_t>(h.w - h.z) * static_cast<uint32_t>(G) + task_cost * h.y + chunk_cost;
+        }
+        uint32_t cut[kXcds + 1];
+        cut[0] = 0;
+        cut[kXcds] = n_real;
+        for (uint32_t x = 1; x < kXcds; ++x) {
+            const uint64_t want = cum[n_real] * x / kXcds;
+            uint32_t c = static_cast<uint32_t>(std::lower_bound(cum.begin(), cum.end(), want) - cum.begin());
+            c = (c + kWavesPerBlock / 2) / kWavesPerBlock * kWavesPerBlock;  // whole workgroups
+            cut[x] = std::clamp(c, cut[x - 1], n_real);
+        }
+        uint32_t longest = 0;
+        for (uint32_t x = 0; x < kXcds; ++x) longest = std::max(longest, cut[x + 1] - cut[x]);
+        longest = (longest + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock;
+        chunk.assign(static_cast<size_t>(longest) * kXcds, make_uint4(0u, 0u, 0u, 0u));  // empty: no tasks, no records
+        for (uint32_t x = 0; x < kXcds; ++x)
+            for (uint32_t c = cut[x]; c < cut[x + 1]; ++c) chunk[static_cast<size_t>(x) * longest + (c - cut[x])] = header(c);
+    } else {
+        chunk.resize(n_real);
+        for (uint32_t c = 0; c < n_real; ++c) chunk[c] = header(c);
+    }
+    p->n_chunks = n_real;
+    p->n_slots = static_cast<uint32_t>(chunk.size());
     if ((rc = upload(&p->d_chunk, chunk, &p->device_bytes))) return rc;
+    if (flags & FLEX_PLAN_STATS) {
+        try {
+            collect_stats(p, rec, chunk, split_nnz);
+        } catch (const std::bad_alloc &) {
+            return FLEX_ERR_NOMEM;
+        }
+    }
     if ((rc = upload(&p->d_split, split, &p->device_bytes))) return rc;
     std::vector<uint32_t> piece_row(n_partials);
     for (uint32_t si = 0; si < split.size(); ++si)
@@ -254,7 +343,7 @@ static int create_common(flex_plan **out, const flex_csr *hostA, int64_t row_beg
     *out = nullptr;
     if (k <= 0 || device < 0) return FLEX_ERR_INVALID;
     const unsigned order = flags & FLEX_ORDER_MASK;
-    if (order > FLEX_ORDER_GORDER) return FLEX_ERR_INVALID;
+    if (order > FLEX_ORDER_GORDER || (flags & ~(FLEX_ORDER_MASK | FLEX_PLAN_STATS))) return FLEX_ERR_INVALID;
     int rc = validate_csr(hostA);
     if (rc) return rc;
     if (hostA->m >= INT32_MAX) return FLEX_ERR_UNSUPPORTED;
@@ -319,7 +408,7 @@ int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream) {
                       ((reinterpret_cast<uintptr_t>(dB) | reinterpret_cast<uintptr_t>(dC)) % 16 == 0);
     const bool fused = vec4 && p->fused_fixup;  // the generic kernel always leaves the sum to spmm_fixup_kernel
     PlanView v{p->d_rec, p->d_t_beg, p->d_t_dst, p->d_chunk, p->d_partial, p->d_piece_row, p->d_split, p->d_split_cnt,
-               p->partial_bytes, fused ? 1u : 0u, p->n_chunks, p->k,
+               p->partial_bytes, fused ? 1u : 0u, p->n_slots, p->k,
                p->xcd_remap ? 1u : 0u, p->lds_extra, p->trace};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc = launch_spmm(v, p->lanes_per_nz, p->off32, vec4, dB, dC, s);
@@ -354,6 +443,14 @@ int flex_plan_get_info(const flex_plan *p, flex_plan_info *o) {
     o->lanes_per_nz = p->lanes_per_nz;
     o->order = static_cast<int32_t>(p->order);
     o->plan_ms = p->plan_ms;
+    o->n_slots = p->n_slots;
+    return FLEX_OK;
+}
+
+int flex_plan_get_stats(const flex_plan *p, flex_plan_stats *o) {
+    if (!p || !o) return FLEX_ERR_INVALID;
+    if (!p->has_stats) return FLEX_ERR_UNSUPPORTED;
+    *o = p->stats;
     return FLEX_OK;
 }
 

@@ -367,6 +367,7 @@ __global__ __launch_bounds__(64 * WPB) void spmm_flat_kernel(PlanView p, const f
     // load per array and are handed out with v_readlane; the header carries the record range, so
     // the record fetch does not wait for them: header -> {descriptors, records} -> gathers.
     const uint4 hdr = p.chunk[chunk];
+    if (hdr.y == 0) return;  // an empty entry that pads this XCD's slice of the table (plan.cpp)
     const uint32_t my_beg = (static_cast<uint32_t>(lane) <= hdr.y) ? p.t_beg[hdr.x + lane] : 0u;
     const uint32_t my_dst = (static_cast<uint32_t>(lane) < hdr.y) ? p.t_dst[hdr.x + lane] : 0u;
     compute_chunk<G, OFF32, U>(p, hdr, my_beg, my_dst, false, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok);

@@ -62,6 +62,7 @@ typedef struct flex_plan flex_plan;
                                  no-permutation contract as FLEX_ORDER_RCM */
 #define FLEX_ORDER_GORDER 3u  /* rows scheduled in Gorder(window 3) order (≙ DataLoaderGorder, DataLoader.cu:789-857) */
 #define FLEX_ORDER_MASK 0xFu
+#define FLEX_PLAN_STATS 0x100u /* also collect flex_plan_stats while planning (one extra pass over the records) */
 
 /* ≙ Mat::Mat + csr2_DiagTiling + alpha_transfer (mat.cu:7-31, 680-942, 268-293):
  * builds the row-panel plan for `hostA` and uploads it to `device`.  The reference's
@@ -99,15 +100,40 @@ typedef struct flex_plan_info {
     int32_t m, n, k, device;
     int64_t nnz;
     int64_t n_tasks;      /* tasks: rows + pieces of split rows */
-    int64_t n_chunks;     /* schedule chunks (runs of tasks) that the persistent waves pull from the queues */
+    int64_t n_chunks;     /* schedule chunks (runs of tasks): one wave each, four to a workgroup */
     int64_t n_split_rows; /* rows long enough to be split over several waves */
     int64_t n_partials;   /* k-wide partial sums held in the workspace */
     int64_t device_bytes; /* HBM held by the plan */
     int32_t lanes_per_nz; /* G: lanes that cooperate on one nonzero (k/4 rounded up to a power of two) */
     int32_t order;        /* FLEX_ORDER_* actually applied */
     double plan_ms;       /* host time spent planning + uploading */
+    int64_t n_slots;      /* chunk-table entries launched: n_chunks + the empty entries that pad the XCD slices */
 } flex_plan_info;
 int flex_plan_get_info(const flex_plan *plan, flex_plan_info *out);
+
+/* ≙ Mat::alpha_stats_collect (mat.cu:944-1065) and the B-Re1 / B-Re2 columns of run()'s table
+ * (flex.cu:5217-5223): how much B-row reuse the schedule exposes to each level of the machine,
+ * and how evenly the work is cut.  "B rows" are distinct column ids; padding records excluded.
+ * Needs FLEX_PLAN_STATS at plan creation, otherwise FLEX_ERR_UNSUPPORTED. */
+typedef struct flex_plan_stats {
+    int64_t records;       /* nnz + per-row padding to whole gather steps */
+    int64_t cols_wave;     /* sum over chunks of distinct B rows  (≙ n_col_sum: reuse inside one unit of work) */
+    int64_t cols_wg;       /* sum over workgroups (4 chunks, one CU's L1) */
+    int64_t cols_xcd;      /* sum over the 8 XCD slices of the chunk table (≙ acc_col: reuse inside one L2) */
+    double reuse_wave;     /* nnz / cols_wave  -- B-Re1: 1 = none, ideal = average degree */
+    double reuse_wg;       /* nnz / cols_wg */
+    double reuse_xcd;      /* nnz / cols_xcd   -- B-Re2 */
+    double gather_bytes;   /* no-reuse gather model: 4(n+1) + 8 nnz + 4 nnz k + 4 n k   (u = 1) */
+    double l2_bytes;       /* same with B rows fetched once per XCD: 4(n+1) + 8 records + 4 k cols_xcd + 4 m k */
+    int64_t chunk_rec_max; /* largest chunk, records */
+    double chunk_rec_mean;
+    double chunk_imb_pct;  /* 100 max/mean - 100   (≙ "wp imb") */
+    double xcd_imb_pct;    /* records per XCD slice, 100 max/mean - 100   (≙ "sm imb") */
+    double split_nnz_pct;  /* share of nonzeros in rows cut into pieces (≙ share of work needing atomics) */
+    double pad_pct;        /* 100 (records - nnz) / nnz */
+    int64_t n_workgroups;
+} flex_plan_stats;
+int flex_plan_get_stats(const flex_plan *plan, flex_plan_stats *out);
 
 /* ≙ flexspmm_v9_permuteX (flex.cu:276-289): dst[r,:] = src[idx[r],:], n rows of k floats.
  * Not needed by flex_spmm (plans fold the permutation in); provided for callers that

@@ -373,3 +373,44 @@ def test_cxx_multi_gpu_driver_on_one_device():
     rows = [json.loads(line) for line in out.stdout.splitlines() if line.startswith("{")]
     mg = [r for r in rows if r["ord"] == "MG"]
     assert len(mg) == 1 and mg[0]["errs"] == 0 and mg[0]["gpus"] == 1
+
+
+def test_plan_stats_reuse_and_imbalance_report():
+    """≙ alpha_stats_collect / B-Re1 / B-Re2 (mat.cu:944-1065, flex.cu:5217-5223): invariants of the report."""
+    from flex_amd import FLEX_PLAN_STATS, FlexError
+    n = 4096
+    # (1) diagonal: no B row is ever reused
+    rp = np.arange(n + 1, dtype=np.uint32)
+    a = flex_amd.HostCsr(rp, np.arange(n, dtype=np.uint32), np.ones(n, np.float32), n=n)
+    st = Plan(a, 32, order=FLEX_ORDER_NATURAL | FLEX_PLAN_STATS).stats()
+    assert st["cols_wave"] == st["cols_wg"] == st["cols_xcd"] == n
+    assert st["reuse_wave"] == st["reuse_xcd"] == 1.0 and st["split_nnz_pct"] == 0.0
+    assert st["records"] == n * 8 and abs(st["pad_pct"] - 700.0) < 1e-9  # k=32: 8 records per gather step
+    # (2) every row reads the same 16 B rows: one fetch per chunk / workgroup / XCD slice
+    deg = 16
+    rp = (np.arange(n + 1) * deg).astype(np.uint32)
+    col = np.tile(np.arange(deg, dtype=np.uint32) * 7, n)
+    a = flex_amd.HostCsr(rp, col, np.ones(n * deg, np.float32), n=n)
+    p = Plan(a, 128, order=FLEX_ORDER_NATURAL | FLEX_PLAN_STATS)
+    st, info = p.stats(), p.info()
+    assert st["cols_wave"] == deg * info["n_chunks"]
+    assert st["cols_wg"] == deg * -(-info["n_chunks"] // 4)
+    assert st["cols_xcd"] == deg * 8 and st["n_workgroups"] % 8 == 0
+    assert st["records"] == info["nnz"] and st["pad_pct"] == 0.0
+    assert st["gather_bytes"] == 4.0 * (n + 1) + 8.0 * n * deg + 4.0 * n * deg * 128 + 4.0 * n * 128
+    assert st["chunk_imb_pct"] >= 0.0 and st["xcd_imb_pct"] >= 0.0
+    # (3) ragged graph: ordering of the counts, split share, and the report leaves the result alone
+    a = random_csr(3000, 3000, 12, seed=5, long_rows={7: 2500, 11: 900})
+    B = random_B(3000, 64, 1)
+    p = Plan(a, 64, order=flex_amd.FLEX_ORDER_CLUSTER | FLEX_PLAN_STATS)
+    st = p.stats()
+    distinct = len(np.unique(a.col))
+    assert st["cols_wave"] >= st["cols_wg"] >= st["cols_xcd"] >= distinct
+    assert st["records"] >= a.nnz and 0.0 < st["split_nnz_pct"] < 100.0
+    assert st["split_nnz_pct"] >= 100.0 * (2500 + 900) / a.nnz - 1e-6  # the two planted long rows are cut
+    assert_matches_oracle(a, B, run_plan(p, B))
+    # (4) not collected unless asked for; unknown flag bits are refused
+    with pytest.raises(FlexError):
+        Plan(a, 64).stats()
+    with pytest.raises(FlexError):
+        Plan(a, 64, order=0x200)

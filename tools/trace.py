@@ -25,7 +25,7 @@ def main():
     C = torch.empty((a.m, k), device="cuda")
     p = flex_amd.Plan(a, k, order=order)
     info = p.info()
-    nw = info['n_chunks']
+    nw = info['n_slots']
     log = torch.zeros((nw, 12), dtype=torch.int64, device="cuda")
     L = flex_amd.lib()
     L.flex_debug_set_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -37,7 +37,7 @@ def main():
     p.spmm(B.data_ptr(), C.data_ptr(), s)
     torch.cuda.synchronize()
     t = log.cpu().numpy()
-    t = t[t[:, 1] != 0]
+    t = t[(t[:, 1] != 0) & (t[:, 3] > 0)]  # drop the empty slots that pad the XCD slices
     xcc, t0, t1, nrec, nch, home = t[:, 0], t[:, 1], t[:, 2], t[:, 3], t[:, 4], t[:, 5]
     base = t0.min()
     tick = 0.01  # s_memrealtime: 100 MHz -> 0.01 us per tick
