@@ -31,5 +31,17 @@ for name, d in res.items():
         d["fetch_MB_x2"] = 2 * d["FETCH_SIZE"] / 1e3
     if "WRITE_SIZE" in d:
         d["write_MB"] = d["WRITE_SIZE"] / 1e3
+# measured B reuse u (≙ flex.cu:5513-5528) when the bench line with n, nnz, k is in kt.log
+try:
+    cfg = None
+    for line in open(f"{out}/kt.log"):
+        if line.startswith("{") and '"config"' in line:
+            cfg = json.loads(line)["config"]
+    for name, d in res.items():
+        if cfg and "fetch_MB_x2" in d:
+            nnz, n, k = cfg["nnz"], cfg["n"], cfg["k"]
+            d["u_l2"] = 4.0 * nnz * k / max(1.0, d["fetch_MB_x2"] * 1e6 - 8.0 * nnz - 4.0 * (n + 1))
+except (OSError, KeyError, ValueError):
+    pass
 print(json.dumps(res, indent=1))
 json.dump(res, open(f"{out}/summary.json", "w"), indent=1)
