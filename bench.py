@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + FLEX_BENCH_DEVICE=0 rehearses the N>1 path on a one-GPU box (not a measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-copy-probe", action="store_true", help="skip the streaming read / copy probe that measures achievable HBM GB/s")
     ap.add_argument("--no-vendor", action="store_true", help="skip the hipSPARSE side-by-side (N=1 only)")
     ap.add_argument("--check", action="store_true", help="verify rank 0's shard against the oracle (small workloads)")
     return ap.parse_args()
@@ -82,7 +83,8 @@ def main():
     order = {"cluster": flex_amd.FLEX_ORDER_CLUSTER, "rcm": flex_amd.FLEX_ORDER_RCM,
              "natural": flex_amd.FLEX_ORDER_NATURAL}[args.order]
     if world == 1:
-        plan = flex_amd.Plan(a, k, device=local_rank, order=order)
+        want_stats = a.nnz <= 50_000_000  # one extra pass over the records: skipped on amazon-size inputs
+        plan = flex_amd.Plan(a, k, device=local_rank, order=order | (flex_amd.FLEX_PLAN_STATS if want_stats else 0))
         shard_nnz, shard_rows = a.nnz, a.m
         shard = None
     else:
@@ -183,6 +185,17 @@ def main():
                          "kernel": "spmm_flat_kernel", "kernel_ms": round(kern_ms, 6),
                          "algorithmic_bytes_per_launch": int(b_alg)},
         }
+        if world == 1 and want_stats:  # ≙ B-Re1 / B-Re2 and alpha_stats_collect (flex.cu:5217-5223, mat.cu:944-1065)
+            st = plan.stats()
+            out["config"]["plan"].update({
+                "b_reuse_wave": round(st["reuse_wave"], 3), "b_reuse_xcd": round(st["reuse_xcd"], 3),
+                "chunk_imb_pct": round(st["chunk_imb_pct"], 1), "xcd_imb_pct": round(st["xcd_imb_pct"], 2),
+                "split_nnz_pct": round(st["split_nnz_pct"], 2), "pad_pct": round(st["pad_pct"], 2)})
+        if world == 1 and not args.no_copy_probe:
+            # achievable HBM bandwidth on this box, measured by the library's own streaming kernels
+            pr = flex_amd.hbm_probe(local_rank, mib=2048, reps=10)
+            out["roofline"]["hbm_read_GBps_measured"] = round(pr["read_GBps"], 1)
+            out["roofline"]["hbm_copy_GBps_measured"] = round(pr["copy_GBps"], 1)
         if ok is not None:
             out["check"] = ok
         if world == 1 and not args.no_vendor:

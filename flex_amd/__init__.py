@@ -20,6 +20,10 @@ from .binding import (  # noqa: F401
     csv_save,
     csr_load_bin,
     csr_save_bin,
+    csr_fingerprint,
+    hbm_probe,
+    perm_load,
+    perm_save,
     mtx_load,
     fill_dense_rand,
     gather_rows,

@@ -70,8 +70,8 @@ class _SynthParams(C.Structure):  # flex_synth_params
 # every symbol include/flex_spmm.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = [
     "flex_plan_create", "flex_plan_create_mapped", "flex_plan_create_rows", "flex_spmm",
-    "flex_plan_destroy", "flex_plan_get_info", "flex_plan_get_stats", "flex_gather_rows", "flex_csv_load", "flex_mtx_load",
-    "flex_csv_save", "flex_csr_save_bin", "flex_csr_load_bin",
+    "flex_plan_destroy", "flex_plan_get_info", "flex_plan_get_stats", "flex_hbm_probe", "flex_gather_rows", "flex_csv_load", "flex_mtx_load",
+    "flex_csv_save", "flex_csr_save_bin", "flex_csr_load_bin", "flex_csr_fingerprint", "flex_perm_save", "flex_perm_load",
     "flex_host_csr_free", "flex_fill_dense_rand", "flex_order_rcm", "flex_order_cluster", "flex_order_gorder", "flex_perm_csr",
     "flex_order_deg", "flex_order_dfs", "flex_shard_rows", "flex_synth_graph", "flex_synth_preset", "flex_strerror", "flex_last_hip_error",
     "flex_last_hip_error_string", "flex_abi_version",
@@ -116,9 +116,14 @@ def lib():
         L.flex_plan_get_info.argtypes = [vp, C.POINTER(_PlanInfo)]
         L.flex_plan_get_stats.argtypes = [vp, C.POINTER(_PlanStats)]
         L.flex_gather_rows.argtypes = [vp, vp, vp, i64, i32, vp]
+        L.flex_hbm_probe.argtypes = [i32, i64, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.flex_csv_load.argtypes = [C.c_char_p, C.POINTER(_HostCsr)]
         L.flex_mtx_load.argtypes = [C.c_char_p, i32, C.POINTER(_HostCsr)]
         L.flex_csv_save.argtypes = [C.c_char_p, C.POINTER(_Csr)]
+        L.flex_csr_fingerprint.argtypes = [C.POINTER(_Csr)]
+        L.flex_csr_fingerprint.restype = C.c_uint64
+        L.flex_perm_save.argtypes = [C.c_char_p, vp, i64, C.c_uint64]
+        L.flex_perm_load.argtypes = [C.c_char_p, vp, i64, C.c_uint64]
         L.flex_csr_save_bin.argtypes = [C.c_char_p, C.POINTER(_Csr)]
         L.flex_csr_load_bin.argtypes = [C.c_char_p, C.POINTER(_HostCsr)]
         L.flex_host_csr_free.argtypes = [C.POINTER(_HostCsr)]
@@ -208,6 +213,29 @@ def csr_load_bin(path: str) -> HostCsr:
     s = _HostCsr()
     _check(lib().flex_csr_load_bin(os.fsencode(path), C.byref(s)), f"flex_csr_load_bin({path})")
     return _take(s)
+
+
+def hbm_probe(device: int = 0, mib: int = 2048, reps: int = 10) -> dict:
+    """Measured GB/s of a read-only stream and of a copy (read + write bytes) on `device`."""
+    r, c = C.c_double(), C.c_double()
+    _check(lib().flex_hbm_probe(device, mib << 20, reps, C.byref(r), C.byref(c)), "flex_hbm_probe")
+    return {"read_GBps": r.value, "copy_GBps": c.value}
+
+
+def csr_fingerprint(a: HostCsr) -> int:
+    v = a.view()
+    return int(lib().flex_csr_fingerprint(C.byref(v)))
+
+
+def perm_save(path: str, rank, fingerprint: int):
+    r = np.ascontiguousarray(rank, dtype=np.uint32)
+    _check(lib().flex_perm_save(os.fsencode(path), r.ctypes.data, len(r), fingerprint), f"flex_perm_save({path})")
+
+
+def perm_load(path: str, n: int, fingerprint: int) -> np.ndarray:
+    rank = np.empty(max(n, 1), dtype=np.uint32)
+    _check(lib().flex_perm_load(os.fsencode(path), rank.ctypes.data, n, fingerprint), f"flex_perm_load({path})")
+    return rank[:n]
 
 
 def fill_dense_rand(n: int, k: int) -> np.ndarray:

@@ -163,39 +163,52 @@ void DataLoader::perm_apply(const DataLoader &dl) {
     }
 }
 
-DataLoaderRcm::DataLoaderRcm(const DataLoader &dl) : DataLoader(dl) {
-    std::vector<uint32_t> rank(n);
+namespace {
+
+// rank[old] = new from `compute`, or from <perm_cache>/<graph>.<ORD>.perm when that file matches this
+// matrix (the reference recomputes every ordering on every run).
+template <typename F>
+std::vector<uint32_t> cached_rank(const DataLoader &dl, const char *abbr, F compute) {
+    std::vector<uint32_t> rank(dl.n);
     const flex_csr a = dl.csr_view();
-    FLEX_CHECK(flex_order_rcm(&a, rank.data()));
-    adopt_rank(dl, rank, "RCM");
+    const std::string &dir = run_options().perm_cache;
+    std::string path;
+    uint64_t fp = 0;
+    if (!dir.empty()) {
+        path = dir + "/" + dl.graph_name + "." + abbr + ".perm";
+        fp = flex_csr_fingerprint(&a);
+        if (flex_perm_load(path.c_str(), rank.data(), static_cast<int64_t>(dl.n), fp) == FLEX_OK) {
+            std::printf("%s order: cached (%s)\n", abbr, path.c_str());
+            return rank;
+        }
+    }
+    FLEX_CHECK(compute(&a, rank.data()));
+    if (!dir.empty() && flex_perm_save(path.c_str(), rank.data(), static_cast<int64_t>(dl.n), fp) != FLEX_OK)
+        std::printf("warning: could not write %s\n", path.c_str());
+    return rank;
+}
+
+}  // namespace
+
+DataLoaderRcm::DataLoaderRcm(const DataLoader &dl) : DataLoader(dl) {
+    adopt_rank(dl, cached_rank(dl, "RCM", [](const flex_csr *a, uint32_t *r) { return flex_order_rcm(a, r); }), "RCM");
 }
 
 DataLoaderDeg::DataLoaderDeg(const DataLoader &dl) : DataLoader(dl) {
-    std::vector<uint32_t> rank(n);
-    const flex_csr a = dl.csr_view();
-    FLEX_CHECK(flex_order_deg(&a, /*descending=*/1, rank.data()));
-    adopt_rank(dl, rank, "DEG");
+    adopt_rank(dl, cached_rank(dl, "DEG", [](const flex_csr *a, uint32_t *r) { return flex_order_deg(a, /*descending=*/1, r); }), "DEG");
 }
 
 DataLoaderDFS::DataLoaderDFS(const DataLoader &dl) : DataLoader(dl) {
-    std::vector<uint32_t> rank(n);
-    const flex_csr a = dl.csr_view();
-    FLEX_CHECK(flex_order_dfs(&a, rank.data()));
-    adopt_rank(dl, rank, "DFS");
+    adopt_rank(dl, cached_rank(dl, "DFS", [](const flex_csr *a, uint32_t *r) { return flex_order_dfs(a, r); }), "DFS");
 }
 
 DataLoaderGorder::DataLoaderGorder(const DataLoader &dl) : DataLoader(dl) {
-    std::vector<uint32_t> rank(n);
-    const flex_csr a = dl.csr_view();
-    FLEX_CHECK(flex_order_gorder(&a, /*window_sz=*/3, rank.data()));  // DataLoader.cu:808
-    adopt_rank(dl, rank, "GOR");
+    // window 3 as DataLoader.cu:808
+    adopt_rank(dl, cached_rank(dl, "GOR", [](const flex_csr *a, uint32_t *r) { return flex_order_gorder(a, /*window_sz=*/3, r); }), "GOR");
 }
 
 DataLoaderRabbit::DataLoaderRabbit(const DataLoader &dl) : DataLoader(dl) {
-    std::vector<uint32_t> rank(n);
-    const flex_csr a = dl.csr_view();
-    FLEX_CHECK(flex_order_cluster(&a, rank.data()));
-    adopt_rank(dl, rank, "RBT");
+    adopt_rank(dl, cached_rank(dl, "RBT", [](const flex_csr *a, uint32_t *r) { return flex_order_cluster(a, r); }), "RBT");
 }
 
 void DataLoader::getDegDist() {  // DataLoader.cu:126-145

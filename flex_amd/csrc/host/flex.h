@@ -8,6 +8,9 @@ struct RunOptions {
     bool json = false;           // one JSON line per configuration instead of the table only
     bool vendor = true;          // run hipSPARSE as gold + baseline (false: CPU-free self check only)
     bool stats = false;          // print each plan's imbalance / reuse summary (≙ alpha_stats_collect)
+    std::string csv;             // append one line per configuration (≙ flex-tile-nperf.csv, flex.cu:4945-4947)
+    std::string stats_log;       // write every plan's summary there (≙ flex-tile-stats2.log, flex.cu:4943-4944)
+    std::string perm_cache;      // directory of cached orderings (<graph>.<ORD>.perm); empty = recompute every run
     int gpus = 0;                // > 0: also run the row-sharded multi-GPU path on that many devices (flex_mg.h)
 };
 RunOptions &run_options();

@@ -1,5 +1,5 @@
 // main.cpp (host mirror) -- ≙ main.cu:7-83 (the non-AXW path): flex <csv|synth:name[*scale]> <k>
-// [--iters N] [--warmup N] [--json] [--stats] [--no-vendor] [--gpus N]
+// [--iters N] [--warmup N] [--json] [--stats] [--perm-cache DIR] [--csv FILE] [--stats-log FILE] [--no-vendor] [--gpus N]
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -8,12 +8,15 @@
 
 int main(int argc, char *argv[]) {
     if (argc < 3) {
-        std::fprintf(stderr, "usage: %s <graph.csv | synth:name[*scale]> <k> [--iters N] [--warmup N] [--json] [--stats] [--no-vendor] [--gpus N]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <graph.csv | synth:name[*scale]> <k> [--iters N] [--warmup N] [--json] [--stats] [--perm-cache DIR] [--csv FILE] [--stats-log FILE] [--no-vendor] [--gpus N]\n", argv[0]);
         return 2;
     }
     for (int i = 3; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--json")) run_options().json = true;
         else if (!std::strcmp(argv[i], "--stats")) run_options().stats = true;
+        else if (!std::strcmp(argv[i], "--perm-cache") && i + 1 < argc) run_options().perm_cache = argv[++i];
+        else if (!std::strcmp(argv[i], "--csv") && i + 1 < argc) run_options().csv = argv[++i];
+        else if (!std::strcmp(argv[i], "--stats-log") && i + 1 < argc) run_options().stats_log = argv[++i];
         else if (!std::strcmp(argv[i], "--no-vendor")) run_options().vendor = false;
         else if (!std::strcmp(argv[i], "--gpus") && i + 1 < argc) run_options().gpus = std::atoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--iters") && i + 1 < argc) run_options().iters = std::atoi(argv[++i]);

@@ -96,7 +96,7 @@ struct Row {
 };
 
 void bench_one(DataLoader &dl, unsigned schedule, const char *sched_name, const DataLoader &gold_src, float *h_res,
-               Perfs &perfRes, std::vector<Row> &rows) {
+               Perfs &perfRes, std::vector<Row> &rows, FILE *stats_log) {
     const RunOptions &o = run_options();
     Mat mat(dl, 0, 0);
     mat.schedule = schedule;
@@ -106,6 +106,10 @@ void bench_one(DataLoader &dl, unsigned schedule, const char *sched_name, const 
     if (o.stats) {
         std::printf("%s/%s:\n", dl.vertex_order_abbr.c_str(), sched_name);
         mat.alpha_stats_collect(stdout);
+    }
+    if (stats_log) {
+        std::fprintf(stats_log, "%s/%s k=%d:\n", dl.vertex_order_abbr.c_str(), sched_name, mat.k);
+        mat.alpha_stats_collect(stats_log);
     }
     hipEvent_t e0, e1;
     HIP_CHECK(hipEventCreate(&e0));
@@ -140,36 +144,54 @@ void run(DataLoader &input_vo) {
     if (o.vendor) input_vo.c_cuSpmm_run(perfRes);  // gold + vendor baseline (flex.cu:4569)
     std::unique_ptr<float[]> h_res(new float[std::max<int64_t>(input_vo.C_elts, 1)]);
     std::vector<Row> rows;
+    FILE *stats_log = o.stats_log.empty() ? nullptr : std::fopen(o.stats_log.c_str(), "w");
+    if (!o.stats_log.empty() && !stats_log) throw std::runtime_error("cannot open " + o.stats_log);
+    if (stats_log) std::printf("Writing detailed statistics to file %s\n", o.stats_log.c_str());
 
     // engine-side schedules on the original loader (no permuted CSR, no permuteX pass)
-    bench_one(input_vo, FLEX_ORDER_NATURAL, "natural", input_vo, h_res.get(), perfRes, rows);
-    bench_one(input_vo, FLEX_ORDER_RCM, "rcm", input_vo, h_res.get(), perfRes, rows);
-    bench_one(input_vo, FLEX_ORDER_CLUSTER, "cluster", input_vo, h_res.get(), perfRes, rows);
+    bench_one(input_vo, FLEX_ORDER_NATURAL, "natural", input_vo, h_res.get(), perfRes, rows, stats_log);
+    bench_one(input_vo, FLEX_ORDER_RCM, "rcm", input_vo, h_res.get(), perfRes, rows, stats_log);
+    bench_one(input_vo, FLEX_ORDER_CLUSTER, "cluster", input_vo, h_res.get(), perfRes, rows, stats_log);
     // the reference's flow: reordered loaders (flex.cu:4572-4576), plan folds vo_mp back in
     {
         DataLoaderRcm rcm(input_vo);
-        bench_one(rcm, FLEX_ORDER_NATURAL, "natural", input_vo, h_res.get(), perfRes, rows);
+        bench_one(rcm, FLEX_ORDER_NATURAL, "natural", input_vo, h_res.get(), perfRes, rows, stats_log);
     }
     {
         DataLoaderRabbit rbt(input_vo);
-        bench_one(rbt, FLEX_ORDER_NATURAL, "natural", input_vo, h_res.get(), perfRes, rows);
+        bench_one(rbt, FLEX_ORDER_NATURAL, "natural", input_vo, h_res.get(), perfRes, rows, stats_log);
     }
     {
         DataLoaderDFS dfs(input_vo);
-        bench_one(dfs, FLEX_ORDER_NATURAL, "natural", input_vo, h_res.get(), perfRes, rows);
+        bench_one(dfs, FLEX_ORDER_NATURAL, "natural", input_vo, h_res.get(), perfRes, rows, stats_log);
     }
     try {
         DataLoaderGorder gor(input_vo);
-        bench_one(gor, FLEX_ORDER_NATURAL, "natural", input_vo, h_res.get(), perfRes, rows);
+        bench_one(gor, FLEX_ORDER_NATURAL, "natural", input_vo, h_res.get(), perfRes, rows, stats_log);
     } catch (const std::runtime_error &e) {
         // Gorder cannot order a graph with an isolated vertex (nor can the reference, unitheap.cu:35-38)
         std::printf("GOR  skipped: %s\n", e.what());
     }
     {
         DataLoaderDeg deg(input_vo);
-        bench_one(deg, FLEX_ORDER_NATURAL, "natural", input_vo, h_res.get(), perfRes, rows);
+        bench_one(deg, FLEX_ORDER_NATURAL, "natural", input_vo, h_res.get(), perfRes, rows, stats_log);
     }
 
+    if (stats_log) std::fclose(stats_log);
+    if (!o.csv.empty()) {  // appended, graph name first, one line per configuration (flex.cu:4945-4947, 5135-5540)
+        FILE *csv = std::fopen(o.csv.c_str(), "a");
+        if (!csv) throw std::runtime_error("cannot open " + o.csv);
+        std::fprintf(csv, "%s\n", input_vo.graph_name.c_str());
+        std::fprintf(csv, "ord,sched,k,chunks,split,B-Re1,B-Re2,chunk_imb%%,xcd_imb%%,t/us,GFLOP/s,Balg_GB/s,plan_MB,X_MB,C_MB,vendor/us,errs\n");
+        for (const Row &r : rows)
+            std::fprintf(csv, "%3s,%s,%zu,%lld,%lld,%5.2f,%5.2f,%.0f,%.1f,%7.1f,%.1f,%.1f,%6.2f,%6.2f,%6.2f,%.1f,%d\n",
+                         r.ord.c_str(), r.sched.c_str(), input_vo.dim, static_cast<long long>(r.info.n_chunks),
+                         static_cast<long long>(r.info.n_split_rows), r.stats.reuse_wave, r.stats.reuse_xcd,
+                         r.stats.chunk_imb_pct, r.stats.xcd_imb_pct, r.t_us, r.gflops, r.balg_gbs,
+                         r.info.device_bytes * 1e-6, input_vo.gpuX_bytes * 1e-6, input_vo.gpuC_bytes * 1e-6,
+                         perfRes.cuSpmmProcessing, r.errs);
+        std::fclose(csv);
+    }
     const double flops = 2.0 * input_vo.nnz * input_vo.dim;
     if (o.vendor)
         std::printf("hipSPARSE setup/us: %.2f , processing/us: %.2f  (%.1f GFLOP/s)\n", perfRes.cuSpmmSetup,

@@ -392,4 +392,53 @@ int flex_fill_dense_rand(float *hostB, int64_t n, int k) {
     return FLEX_OK;
 }
 
+static const char kPermMagic[8] = {'F', 'L', 'E', 'X', 'P', 'R', 'M', '1'};
+
+uint64_t flex_csr_fingerprint(const flex_csr *A) {
+    if (flex::validate_csr(A)) return 0;
+    // FNV-1a over 64-bit words of (m, n, nnz, rowPtr, col): structure only, values do not change an ordering
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+    mix(static_cast<uint64_t>(A->m));
+    mix(static_cast<uint64_t>(A->n));
+    mix(static_cast<uint64_t>(A->nnz));
+    for (int64_t i = 0; i <= A->m; ++i) mix(A->rowPtr[i]);
+    for (int64_t e = 0; e < A->nnz; ++e) mix(A->col[e]);
+    return h ? h : 1;
+}
+
+int flex_perm_save(const char *path, const uint32_t *rank, int64_t n, uint64_t fingerprint) {
+    if (!path || !rank || n < 0) return FLEX_ERR_INVALID;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return FLEX_ERR_IO;
+    const uint64_t hdr[2] = {static_cast<uint64_t>(n), fingerprint};
+    bool ok = std::fwrite(kPermMagic, 1, 8, f) == 8 && std::fwrite(hdr, sizeof(uint64_t), 2, f) == 2 &&
+              std::fwrite(rank, sizeof(uint32_t), static_cast<size_t>(n), f) == static_cast<size_t>(n);
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? FLEX_OK : FLEX_ERR_IO;
+}
+
+int flex_perm_load(const char *path, uint32_t *rank, int64_t n, uint64_t fingerprint) {
+    if (!path || !rank || n < 0) return FLEX_ERR_INVALID;
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return FLEX_ERR_IO;
+    char magic[8];
+    uint64_t hdr[2];
+    bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, kPermMagic, 8) == 0 &&
+              std::fread(hdr, sizeof(uint64_t), 2, f) == 2 && hdr[0] == static_cast<uint64_t>(n) && hdr[1] == fingerprint &&
+              std::fread(rank, sizeof(uint32_t), static_cast<size_t>(n), f) == static_cast<size_t>(n) && std::fgetc(f) == EOF;
+    std::fclose(f);
+    if (!ok) return FLEX_ERR_FORMAT;
+    try {
+        std::vector<uint8_t> seen(static_cast<size_t>(n), 0);
+        for (int64_t i = 0; i < n; ++i) {
+            if (rank[i] >= static_cast<uint64_t>(n) || seen[rank[i]]) return FLEX_ERR_FORMAT;
+            seen[rank[i]] = 1;
+        }
+    } catch (const std::bad_alloc &) {
+        return FLEX_ERR_NOMEM;
+    }
+    return FLEX_OK;
+}
+
 }  // extern "C"

@@ -466,10 +466,9 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(float *__restrict__ ds
 
 template <int G, bool OFF32, int U>
 int launch_v4(const PlanView &v, const float *dB, float *dC, hipStream_t s) {
-    // persistent grid: enough workgroups to fill every CU (8 x 256 threads each), fewer for tiny plans;
-    // surplus workgroups find the queues empty and leave at once
-    // 2 or 8 waves per workgroup measured the same as 4 (the launch is not dispatch-bound: an empty
-    // kernel over the same grid takes 3.4 us), so the template parameter stays at kWavesPerBlock
+    // one wave per chunk-table entry, kWavesPerBlock entries per workgroup, a multiple of 8 workgroups so
+    // the XCD slices are equal (plan.cpp pads them).  2 or 8 waves per workgroup measured the same as 4
+    // (the launch is not dispatch-bound: an empty kernel over the same grid takes 3.4 us)
     uint32_t nblk = (v.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
     nblk = (nblk + kXcds - 1) / kXcds * kXcds;
     const uint32_t ktiles = (v.k + 4 * G - 1) / (4 * G);

@@ -135,6 +135,12 @@ typedef struct flex_plan_stats {
 } flex_plan_stats;
 int flex_plan_get_stats(const flex_plan *plan, flex_plan_stats *out);
 
+/* What this box's HBM delivers, for the roofline's denominator (verify BW_peak with a
+ * device-to-device copy and report both): GB/s of a read-only streaming pass and of a copy (bytes
+ * read + bytes written) over `bytes`-sized buffers (use >= 1 GiB: the Infinity Cache is 256 MiB),
+ * mean of `reps` launches each.  Allocates and frees 2 x bytes on `device`; synchronises. */
+int flex_hbm_probe(int device, int64_t bytes, int reps, double *read_gbps, double *copy_gbps);
+
 /* ≙ flexspmm_v9_permuteX (flex.cu:276-289): dst[r,:] = src[idx[r],:], n rows of k floats.
  * Not needed by flex_spmm (plans fold the permutation in); provided for callers that
  * keep the reference's B' ("shadow_b") layout. All pointers are device pointers. */
@@ -178,6 +184,15 @@ int flex_csv_save(const char *path, const flex_csr *A);
  * {magic "FLEXCSR1", int64 m, n, nnz} + rowPtr + col + vals. */
 int flex_csr_save_bin(const char *path, const flex_csr *A);
 int flex_csr_load_bin(const char *path, flex_host_csr *out);
+
+/* Permutation cache (the reference recomputes every ordering on every run): `rank`
+ * (rank[old] = new, n entries) as a small binary file keyed by a 64-bit fingerprint of the CSR
+ * structure (flex_csr_fingerprint: n, nnz, rowPtr, col), so a stale file is refused, not applied.
+ * flex_perm_load returns FLEX_ERR_IO if the file is absent, FLEX_ERR_FORMAT if it is not a
+ * permutation of 0..n-1 or was written for another matrix. */
+uint64_t flex_csr_fingerprint(const flex_csr *A);
+int flex_perm_save(const char *path, const uint32_t *rank, int64_t n, uint64_t fingerprint);
+int flex_perm_load(const char *path, uint32_t *rank, int64_t n, uint64_t fingerprint);
 
 /* ≙ cpuX fill in DataLoader::cuda_alloc_cpy (DataLoader.cu:198-209), glibc rand() stream. */
 int flex_fill_dense_rand(float *hostB, int64_t n, int k);

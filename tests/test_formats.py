@@ -100,3 +100,40 @@ def test_csv_and_binary_round_trip_pubmed(tmp_path):
         f.write(b"not a csr file at all")
     with pytest.raises(flex_amd.FlexError, match="does not parse"):
         flex_amd.csr_load_bin(str(tmp_path / "junk.bin"))
+
+
+def test_permutation_cache_round_trip_and_refusals(tmp_path, golden):
+    """flex_perm_save / flex_perm_load: a cached ordering comes back bit-identical, and a file
+    that is stale (other matrix), truncated, or not a permutation is refused instead of applied."""
+    a = flex_amd.csv_load(os.path.join(GOLDEN, "pubmed.csv"))
+    fp = flex_amd.csr_fingerprint(a)
+    assert fp != 0 and fp == flex_amd.csr_fingerprint(flex_amd.csv_load(os.path.join(GOLDEN, "pubmed.csv")))
+    rank = flex_amd.order_rcm(a)
+    path = str(tmp_path / "pubmed.RCM.perm")
+    flex_amd.perm_save(path, rank, fp)
+    back = flex_amd.perm_load(path, a.n, fp)
+    assert np.array_equal(back, rank)
+    vo = np.empty(a.n, dtype=np.int64)
+    vo[back] = np.arange(a.n)
+    assert np.array_equal(vo.astype(np.int32), golden["pubmed_rcm_vo_mp"])  # still the reference's RCM
+    # values do not enter the fingerprint (they do not change an ordering); structure does
+    a2 = flex_amd.HostCsr(a.rowPtr.copy(), a.col.copy(), a.vals * 2, n=a.n)
+    assert flex_amd.csr_fingerprint(a2) == fp
+    col2 = a.col.copy()
+    col2[0], col2[1] = col2[1], col2[0]
+    assert flex_amd.csr_fingerprint(flex_amd.HostCsr(a.rowPtr.copy(), col2, a.vals.copy(), n=a.n)) != fp
+    with pytest.raises(flex_amd.FlexError):  # absent
+        flex_amd.perm_load(str(tmp_path / "nope.perm"), a.n, fp)
+    with pytest.raises(flex_amd.FlexError, match="does not parse"):  # written for another matrix
+        flex_amd.perm_load(path, a.n, fp ^ 1)
+    with pytest.raises(flex_amd.FlexError, match="does not parse"):  # wrong length
+        flex_amd.perm_load(path, a.n - 1, fp)
+    raw = open(path, "rb").read()
+    open(tmp_path / "short.perm", "wb").write(raw[:-4])
+    with pytest.raises(flex_amd.FlexError, match="does not parse"):
+        flex_amd.perm_load(str(tmp_path / "short.perm"), a.n, fp)
+    dup = rank.copy()
+    dup[5] = dup[6]
+    flex_amd.perm_save(str(tmp_path / "dup.perm"), dup, fp)
+    with pytest.raises(flex_amd.FlexError, match="does not parse"):  # not a permutation
+        flex_amd.perm_load(str(tmp_path / "dup.perm"), a.n, fp)

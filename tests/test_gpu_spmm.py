@@ -231,7 +231,7 @@ def test_large_properties_checksum_and_linearity():
         assert np.all(np.abs(C1[r] - ref) <= 4 * np.finfo(np.float32).eps * len(cols) * np.maximum(1, np.abs(ref)))
 
 
-def test_cxx_host_mirror_cli_pubmed_and_amat():
+def test_cxx_host_mirror_cli_pubmed_and_amat(tmp_path):
     """The C++ DataLoader/Mat/run mirror (flex_amd/lib/flex): hipSPARSE gold + resCheck, every
     ordering must report zero mismatches (≙ assert(!count), flex.cu:4205)."""
     import json
@@ -239,13 +239,28 @@ def test_cxx_host_mirror_cli_pubmed_and_amat():
     exe = os.path.join(os.path.dirname(flex_amd.lib_path()), "flex")
     assert os.path.exists(exe)
     for path, k in ((os.path.join(GOLDEN, "pubmed.csv"), "32"), (os.path.join(GOLDEN, "a_mat.csv"), "8")):
-        out = subprocess.run([exe, path, k, "--json"], capture_output=True, text=True, timeout=300)
+        csv, log = str(tmp_path / "flex-tile-nperf.csv"), str(tmp_path / "flex-tile-stats2.log")
+        out = subprocess.run([exe, path, k, "--json", "--stats", "--csv", csv, "--stats-log", log, "--perm-cache", str(tmp_path)],
+                             capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
         rows = [json.loads(line) for line in out.stdout.splitlines() if line.startswith("{")]
         assert {(r["ord"], r["schedule"]) for r in rows} >= {("OVO", "natural"), ("OVO", "cluster"), ("RCM", "natural"),
                                                              ("RBT", "natural"), ("DEG", "natural"), ("GOR", "natural"), ("DFS", "natural")}
         assert all(r["errs"] == 0 for r in rows)
-    assert "hipSPARSE setup" in out.stdout
+        assert all(r["b_re1"] >= 1.0 and r["b_re2"] >= r["b_re1"] for r in rows)
+    assert "hipSPARSE setup" in out.stdout and "B reuse: wave" in out.stdout
+    # second run of the same graph: every ordering comes from the permutation cache and still checks out
+    again = subprocess.run([exe, path, k, "--json", "--perm-cache", str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert again.returncode == 0 and "order: cached" not in out.stdout
+    assert all(f"{o} order: cached" in again.stdout for o in ("RCM", "RBT", "DFS", "GOR", "DEG"))
+    assert all(json.loads(ln)["errs"] == 0 for ln in again.stdout.splitlines() if ln.startswith("{"))
+    # the report files of the reference's run(): appended CSV (graph name, header, one line per configuration) ...
+    lines = open(csv).read().splitlines()
+    assert lines.count("pubmed") == 1 and lines.count("a_mat") == 1
+    body = [ln.split(",") for ln in lines if ln[:3] in ("OVO", "RCM", "RBT", "DFS", "GOR", "DEG")]
+    assert len(body) == 2 * 8 and all(row[-1] == "0" for row in body)
+    # ... and the per-plan statistics log (rewritten by each run)
+    assert open(log).read().count("B reuse: wave") == 8
 
 
 def test_vendor_baseline_matches_oracle():
@@ -414,3 +429,11 @@ def test_plan_stats_reuse_and_imbalance_report():
         Plan(a, 64).stats()
     with pytest.raises(FlexError):
         Plan(a, 64, order=0x200)
+
+
+def test_hbm_probe_reports_a_plausible_bandwidth():
+    """flex_hbm_probe: the measured denominator beside the 8 TB/s spec figure."""
+    pr = flex_amd.hbm_probe(0, mib=1024, reps=5)
+    assert 1000.0 < pr["read_GBps"] < 8000.0 and 1000.0 < pr["copy_GBps"] < 8000.0
+    with pytest.raises(flex_amd.FlexError):
+        flex_amd.hbm_probe(0, mib=0)
