@@ -27,8 +27,8 @@
 //    ends.  No barriers: LDS slices are private to a wave.
 //  * C is written once with non-temporal 16-byte stores; rows cut into several
 //    pieces go to k-wide partial slots instead and are summed, in a fixed order,
-//    by a second tiny kernel (deterministic; the reference uses atomicAdd for its
-//    split rows, mat.cu:816-824).
+//    by whichever piece finishes last, inside the same launch (deterministic; the
+//    reference uses atomicAdd for its split rows, mat.cu:816-824).
 #include "internal.h"
 
 namespace flex {
@@ -102,26 +102,21 @@ constexpr int kWindowRecs = 256;  // records staged per wave and window (2 KiB o
 #define FLEX_STAMP(i) do {} while (0)
 #endif
 
-// Records of a window: lane l holds records l, l+64, l+128, l+192 (coalesced 512-B loads).
-struct RecRegs {
-    uint2 r[kWindowRecs / 64];
-};
-
-__device__ __forceinline__ RecRegs load_window(const uint2 *__restrict__ rec, uint32_t wz, uint32_t wn, int lane) {
-    RecRegs w;
+// Stage records [wz, wz+wn) of the stream into the wave's LDS slice: coalesced 512-B loads, lane l takes
+// records l, l+64, l+128, l+192.  Indices are clamped, not predicated (slots >= wn get a copy of the last
+// record and are never read), and the short-window case is a wave-uniform branch: every load is consumed
+// inside its branch, so (a) a long window has its four loads in flight together instead of four round
+// trips and (b) no pending load survives into the gather loop, where the compiler would otherwise put an
+// s_waitcnt vmcnt(0) at the loop head.
+__device__ __forceinline__ void stage_window(uint2 *my_lds, const uint2 *__restrict__ rec, uint32_t wz, uint32_t wn, int lane) {
+    if (wn <= 64) {
+        my_lds[lane] = rec[wz + min(static_cast<uint32_t>(lane), wn - 1)];
+    } else {
+        uint2 r[kWindowRecs / 64];
 #pragma unroll
-    for (int i = 0; i < kWindowRecs / 64; ++i) {
-        const uint32_t idx = i * 64 + lane;
-        w.r[i] = idx < wn ? rec[wz + idx] : make_uint2(0u, 0u);
-    }
-    return w;
-}
-
-__device__ __forceinline__ void store_window(uint2 *my_lds, const RecRegs &w, uint32_t wn, int lane) {
+        for (int i = 0; i < kWindowRecs / 64; ++i) r[i] = rec[wz + min(static_cast<uint32_t>(i * 64 + lane), wn - 1)];
 #pragma unroll
-    for (int i = 0; i < kWindowRecs / 64; ++i) {
-        const uint32_t idx = i * 64 + lane;
-        if (idx < wn) my_lds[idx] = w.r[i];
+        for (int i = 0; i < kWindowRecs / 64; ++i) my_lds[i * 64 + lane] = r[i];
     }
 }
 
@@ -206,7 +201,7 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
     for (uint32_t wz = zb; wz < ze; wz += kWindowRecs) {
         const uint32_t wn = min(static_cast<uint32_t>(kWindowRecs), ze - wz);
         // stage this window's records: coalesced 512-B loads, one ds_write_b64 per lane and load
-        if (!(staged && wz == zb)) store_window(my_lds, load_window(rec, wz, wn, lane), wn, lane);
+        if (!(staged && wz == zb)) stage_window(my_lds, rec, wz, wn, lane);
         FLEX_STAMP(1);  // records -> LDS
 #ifdef FLEX_ABL_STAGEONLY  // timing-only ablation: header, descriptors and records fetched, then leave
         if (p.k > 0) {
