@@ -116,7 +116,7 @@ def lib():
         L.flex_plan_get_info.argtypes = [vp, C.POINTER(_PlanInfo)]
         L.flex_plan_get_stats.argtypes = [vp, C.POINTER(_PlanStats)]
         L.flex_gather_rows.argtypes = [vp, vp, vp, i64, i32, vp]
-        L.flex_hbm_probe.argtypes = [i32, i64, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.flex_hbm_probe.argtypes = [i32, i64, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.flex_csv_load.argtypes = [C.c_char_p, C.POINTER(_HostCsr)]
         L.flex_mtx_load.argtypes = [C.c_char_p, i32, C.POINTER(_HostCsr)]
         L.flex_csv_save.argtypes = [C.c_char_p, C.POINTER(_Csr)]
@@ -215,10 +215,10 @@ def csr_load_bin(path: str) -> HostCsr:
     return _take(s)
 
 
-def hbm_probe(device: int = 0, mib: int = 2048, reps: int = 10) -> dict:
+def hbm_probe(device: int = 0, mib: int = 2048, reps: int = 10, temporal: bool = False) -> dict:
     """Measured GB/s of a read-only stream and of a copy (read + write bytes) on `device`."""
     r, c = C.c_double(), C.c_double()
-    _check(lib().flex_hbm_probe(device, mib << 20, reps, C.byref(r), C.byref(c)), "flex_hbm_probe")
+    _check(lib().flex_hbm_probe(device, mib << 20, reps, int(temporal), C.byref(r), C.byref(c)), "flex_hbm_probe")
     return {"read_GBps": r.value, "copy_GBps": c.value}
 
 

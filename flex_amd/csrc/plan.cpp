@@ -152,9 +152,22 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     if (order != FLEX_ORDER_NATURAL && (A->m != A->n || r0 != 0 || r1 != A->m)) return FLEX_ERR_INVALID;
     p->order = order;
 
-    // 4*G >= min(k,256): G lanes x float4 cover one k-tile
+    // G lanes x float4 cover one column tile of 4*G columns; k wider than that runs as several tiles
+    // (blockIdx.y, dispatched one after the other).  Widest tile (fewest instructions per byte) for
+    // low-degree graphs; high-degree graphs are bound by L2-miss traffic instead -- the B rows touched by
+    // the resident waves (waves x records x 16*G bytes) overflow the 4 MiB L2s -- and a narrower tile
+    // shrinks that footprint at the price of re-reading the records once per tile.  Measured on MI355X,
+    // k=128: reddit-like generator, G=16 vs 32: -7 % at degree 12, +7 % at 24, +15 % at
+    // 36..100; amazon shape +12 % (G=16), +16 % (G=8); flickr (degree 11) -7 %, yelp (19.5) -2.5 %.
+    const double avg_deg = m > 0 ? static_cast<double>(A->rowPtr[r1] - A->rowPtr[r0]) / m : 0.0;
     int G = 8;
     while (4 * G < k && G < 64) G <<= 1;
+    if (const long g_env = env_long("FLEX_LANES", 0); g_env == 8 || g_env == 16 || g_env == 32 || g_env == 64) {
+        G = std::min<int>(G, static_cast<int>(g_env));  // tuning experiments
+    } else {
+        if (avg_deg >= 24.0) G = std::min(G, 16);
+        if (avg_deg >= 128.0) G = std::min(G, 8);
+    }
     p->lanes_per_nz = G;
     p->off32 = static_cast<uint64_t>(A->n) * static_cast<uint64_t>(k) * 4u <= (uint64_t(1) << 32);
 
@@ -175,7 +188,6 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     // chunk budget: short chunks keep the dispatcher's load balancing fine-grained on low-degree
     // graphs (flickr: best at ~96 records), long ones amortise the per-chunk descriptor chain on
     // high-degree graphs (reddit: best at >= 256).  Measured on MI355X, DESIGN.md 3.3.
-    const double avg_deg = m > 0 ? static_cast<double>(A->rowPtr[r1] - A->rowPtr[r0]) / m : 0.0;
     const long auto_budget = std::clamp<long>(static_cast<long>(8.0 * avg_deg), 96, 256);
     const uint32_t wave_nnz = static_cast<uint32_t>(env_long("FLEX_WAVE_NNZ", auto_budget));
     const uint32_t row_cost = static_cast<uint32_t>(env_long("FLEX_ROW_COST", 16));

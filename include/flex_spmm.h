@@ -138,8 +138,11 @@ int flex_plan_get_stats(const flex_plan *plan, flex_plan_stats *out);
 /* What this box's HBM delivers, for the roofline's denominator (verify BW_peak with a
  * device-to-device copy and report both): GB/s of a read-only streaming pass and of a copy (bytes
  * read + bytes written) over `bytes`-sized buffers (use >= 1 GiB: the Infinity Cache is 256 MiB),
- * mean of `reps` launches each.  Allocates and frees 2 x bytes on `device`; synchronises. */
-int flex_hbm_probe(int device, int64_t bytes, int reps, double *read_gbps, double *copy_gbps);
+ * mean of `reps` launches each.  temporal = 0: non-temporal loads (HBM rate at any size beyond L2);
+ * temporal = 1: ordinary loads, so buffers up to the Infinity Cache's size show ITS rate -- the roof
+ * of gathers that miss L2 but whose B is cache-resident (reddit: B = 119 MB).  Allocates and frees
+ * 2 x bytes on `device`; synchronises. */
+int flex_hbm_probe(int device, int64_t bytes, int reps, int temporal, double *read_gbps, double *copy_gbps);
 
 /* ≙ flexspmm_v9_permuteX (flex.cu:276-289): dst[r,:] = src[idx[r],:], n rows of k floats.
  * Not needed by flex_spmm (plans fold the permutation in); provided for callers that
