@@ -165,6 +165,7 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     if (const long g_env = env_long("FLEX_LANES", 0); g_env == 8 || g_env == 16 || g_env == 32 || g_env == 64) {
         G = std::min<int>(G, static_cast<int>(g_env));  // tuning experiments
     } else {
+        G = std::min(G, 32);  // k = 256 as two 128-column tiles beats one 256-column tile on every shape measured
         if (avg_deg >= 24.0) G = std::min(G, 16);
         if (avg_deg >= 128.0) G = std::min(G, 8);
     }

@@ -437,3 +437,22 @@ def test_hbm_probe_reports_a_plausible_bandwidth():
     assert 1000.0 < pr["read_GBps"] < 8000.0 and 1000.0 < pr["copy_GBps"] < 8000.0
     with pytest.raises(flex_amd.FlexError):
         flex_amd.hbm_probe(0, mib=0)
+
+
+@pytest.mark.parametrize("lanes,k", [(64, 256), (32, 256), (16, 128), (8, 128), (8, 64)])
+def test_every_column_tile_width_gives_the_same_answer(monkeypatch, lanes, k):
+    """The planner picks the lanes-per-record G (column tile = 4G) from k and the average degree; every
+    width it can pick -- including G=64, which the default rule never selects -- must pass resCheck,
+    with split rows reduced in-launch across several k-tiles."""
+    a = random_csr(2500, 2500, 30, seed=21, long_rows={3: 2400, 9: 700})
+    B = random_B(2500, k, 4)
+    monkeypatch.setenv("FLEX_LANES", str(lanes))
+    p = Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER)
+    assert p.info()["lanes_per_nz"] == lanes
+    C1 = run_plan(p, B)
+    assert_matches_oracle(a, B, C1)
+    assert np.array_equal(C1, run_plan(p, B))  # deterministic, counters re-armed
+    monkeypatch.delenv("FLEX_LANES")
+    p2 = Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER)
+    assert p2.info()["lanes_per_nz"] == 16  # average degree >= 24: narrow tiles by default
+    assert_matches_oracle(a, B, run_plan(p2, B))
