@@ -8,6 +8,7 @@
 #include <iostream>
 #include <numeric>
 
+#include "../../../include/flex_axw.h"
 #include "flex.h"
 
 namespace {
@@ -113,6 +114,11 @@ void DataLoader::freeAll() {
         freeA();
         if (vertex_order_abbr == "OVO") hip_freez(gpuX);  // reordered loaders alias the original's B (DataLoader.cuh:104)
         hip_freez(gpuC);
+        hip_freez(gpuW);
+        hip_freez(gpuRef1);
+        hip_freez(gpuRef2);
+        if (axw) flex_axw_destroy(axw);
+        axw = nullptr;
     } catch (...) {
     }
 }

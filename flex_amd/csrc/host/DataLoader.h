@@ -12,6 +12,8 @@
 
 #include "common.h"
 
+struct flex_axw;  // include/flex_axw.h
+
 class DataLoader {
    public:
     DataLoader(const std::string &st, const int di);  // DataLoader.cu:9-124
@@ -25,6 +27,8 @@ class DataLoader {
     void perm_apply(const DataLoader &dl);  // DataLoader.cu:244-321: fill this loader from dl through vo_mp (+ checksum self-test)
     void print_data();
     void getDegDist();
+    void axw_alloc();  // W, the two result buffers and the A*X*W plans (host/cusp.cpp); only the --axw path calls it
+    bool compare();    // DataLoader.cu:859-869: cpuRef1 (A(XW)) against cpuRef2 ((AX)W)
 
     const DataLoader *const dl_original;
     std::vector<unsigned int> rowPtr, col;
@@ -33,6 +37,10 @@ class DataLoader {
 
     std::vector<float> cpuX;     // n * dim
     std::vector<float> h_ref_c;  // vendor (hipSPARSE) result, the gold of resCheck
+    std::vector<float> cpuW;     // dim * c                                   (DataLoader.cuh:46)
+    std::vector<float> cpuRef1, cpuRef2;  // n * flex_axw_ld(c): A(XW) and (AX)W  (DataLoader.cuh:47-48)
+    float *gpuW = nullptr, *gpuRef1 = nullptr, *gpuRef2 = nullptr;
+    flex_axw *axw = nullptr;
 
     std::string vertex_order_abbr;
     unsigned int *rowPtr_dev = nullptr, *col_dev = nullptr;

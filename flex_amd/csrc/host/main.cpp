@@ -1,19 +1,21 @@
 // main.cpp (host mirror) -- ≙ main.cu:7-83 (the non-AXW path): flex <csv|synth:name[*scale]> <k>
-// [--iters N] [--warmup N] [--json] [--stats] [--perm-cache DIR] [--csv FILE] [--stats-log FILE] [--no-vendor] [--gpus N]
+// [--iters N] [--warmup N] [--json] [--stats] [--perm-cache DIR] [--csv FILE] [--stats-log FILE] [--no-vendor] [--gpus N] [--axw]
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
 
+#include "cusp.h"
 #include "flex.h"
 
 int main(int argc, char *argv[]) {
     if (argc < 3) {
-        std::fprintf(stderr, "usage: %s <graph.csv | synth:name[*scale]> <k> [--iters N] [--warmup N] [--json] [--stats] [--perm-cache DIR] [--csv FILE] [--stats-log FILE] [--no-vendor] [--gpus N]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <graph.csv | synth:name[*scale]> <k> [--iters N] [--warmup N] [--json] [--stats] [--perm-cache DIR] [--csv FILE] [--stats-log FILE] [--no-vendor] [--gpus N] [--axw]\n", argv[0]);
         return 2;
     }
     for (int i = 3; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--json")) run_options().json = true;
         else if (!std::strcmp(argv[i], "--stats")) run_options().stats = true;
+        else if (!std::strcmp(argv[i], "--axw")) run_options().axw = true;
         else if (!std::strcmp(argv[i], "--perm-cache") && i + 1 < argc) run_options().perm_cache = argv[++i];
         else if (!std::strcmp(argv[i], "--csv") && i + 1 < argc) run_options().csv = argv[++i];
         else if (!std::strcmp(argv[i], "--stats-log") && i + 1 < argc) run_options().stats_log = argv[++i];
@@ -33,6 +35,7 @@ int main(int argc, char *argv[]) {
         std::printf("Nodes zero-deg-in %d, zero-deg-out %d, zero-deg %d\n", data.n_nodes_z_in, data.n_nodes_z_out,
                     data.n_nodes_z_deg);
         std::cout << "NNZ of A: " << data.nnz << std::endl;
+        if (run_options().axw) return run_axw(data);  // ≙ #ifdef AXW, main.cu:22-77
         run(data);  // flex.h / run.cpp
     } catch (const std::exception &e) {
         std::fprintf(stderr, "flex: %s\n", e.what());

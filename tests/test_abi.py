@@ -22,6 +22,25 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert flex_amd.lib().flex_abi_version() == 1
 
 
+@pytest.mark.parametrize("header,lib", [("flex_spmm.h", "libflex_spmm.so"), ("flex_vendor.h", "libflex_vendor.so"),
+                                        ("flex_mg.h", "libflex_mg.so"), ("flex_axw.h", "libflex_axw.so")])
+def test_every_header_symbol_is_exported_by_its_library(header, lib):
+    """include/*.h is the drop-in boundary: each declared entry point must be a defined dynamic symbol of
+    the library named for it (read with nm, so nothing needs a GPU or the vendor runtimes to load)."""
+    hdr = open(os.path.join(ROOT, "include", header)).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)  # prose in comments mentions other libraries' functions
+    declared = set(re.findall(r"\b(flex_[a-z_0-9]+)\s*\(", hdr))
+    assert declared
+    path = os.path.join(os.path.dirname(flex_amd.lib_path()), lib)
+    assert os.path.exists(path), f"{lib} was not built"
+    exported = {ln.split()[-1] for ln in os.popen(f"nm -D --defined-only {path}").read().splitlines() if ln.strip()}
+    assert declared <= exported, declared - exported
+
+
+def test_all_headers_are_covered():
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["flex_axw.h", "flex_mg.h", "flex_spmm.h", "flex_vendor.h"]
+
+
 def test_no_cpu_spmm_symbol_in_product():
     # the product must not carry a CPU SpMM (a fallback would void parity claims)
     out = os.popen(f"nm -D --defined-only {flex_amd.lib_path()}").read()

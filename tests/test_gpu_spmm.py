@@ -249,6 +249,12 @@ def test_cxx_host_mirror_cli_pubmed_and_amat(tmp_path):
         assert all(r["errs"] == 0 for r in rows)
         assert all(r["b_re1"] >= 1.0 and r["b_re2"] >= r["b_re1"] for r in rows)
     assert "hipSPARSE setup" in out.stdout and "B reuse: wave" in out.stdout
+    # the AXW block of main.cu:22-77 (compiled out in the reference): both orders, compared with each other
+    axw = subprocess.run([exe, os.path.join(GOLDEN, "pubmed.csv"), "32", "--axw", "--json"], capture_output=True, text=True, timeout=300)
+    assert axw.returncode == 0, axw.stdout + axw.stderr
+    assert axw.stdout.count("The results are correct..") == 10 and "A(XW):" in axw.stdout and "(AX)W:" in axw.stdout
+    j = [json.loads(ln) for ln in axw.stdout.splitlines() if ln.startswith("{")][-1]
+    assert j["c"] == 3 and j["dim"] == 32 and j["a_xw_ms"] > 0 and j["ax_w_ms"] > 0
     # second run of the same graph: every ordering comes from the permutation cache and still checks out
     again = subprocess.run([exe, path, k, "--json", "--perm-cache", str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert again.returncode == 0 and "order: cached" not in out.stdout
@@ -456,3 +462,35 @@ def test_every_column_tile_width_gives_the_same_answer(monkeypatch, lanes, k):
     p2 = Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER)
     assert p2.info()["lanes_per_nz"] == 16  # average degree >= 24: narrow tiles by default
     assert_matches_oracle(a, B, run_plan(p2, B))
+
+
+@pytest.mark.parametrize("dim,c", [(32, 7), (128, 41), (16, 64)])
+def test_axw_both_orders_match_a_float64_reference(dim, c):
+    """libflex_axw.so (≙ run1 / run2 of cusp.cu): A(XW) and (AX)W agree with each other (the reference's own
+    check, DataLoader.cu:859-869) and with A @ X @ W in float64; padded columns are zero; AUTO takes the
+    order with the narrower SpMM."""
+    import scipy.sparse as sp
+    import torch
+    from flex_amd.axw import FLEX_AXW_A_XW, FLEX_AXW_AX_W, Axw
+    a = random_csr(3000, 3000, 9, seed=31, long_rows={5: 1500})
+    rng = np.random.default_rng(3)
+    X = rng.uniform(-1, 1, size=(a.n, dim)).astype(np.float32)
+    W = rng.uniform(0, 1, size=(dim, c)).astype(np.float32)  # DataLoader.cu:172: W in [0,1)
+    A = sp.csr_matrix((a.vals.astype(np.float64), a.col.astype(np.int64), a.rowPtr.astype(np.int64)), shape=(a.m, a.n))
+    gold = A @ (X.astype(np.float64) @ W.astype(np.float64))
+    scale = np.abs(A) @ (np.abs(X).astype(np.float64) @ np.abs(W).astype(np.float64))  # magnitude of the terms summed
+    h = Axw(a, dim, c)
+    assert h.ld == -(-c // 32) * 32  # whole 128-byte lines per row
+    Xd, Wd = torch.from_numpy(X).cuda(), torch.from_numpy(W).cuda()
+    outs = {}
+    for order in (FLEX_AXW_A_XW, FLEX_AXW_AX_W):
+        out, (gemm_ms, spmm_ms) = h.run(Xd, Wd, order, timed=True)
+        o = out.cpu().numpy()
+        assert gemm_ms > 0 and spmm_ms > 0
+        assert np.all(o[:, c:] == 0)
+        assert np.all(np.abs(o[:, :c] - gold) <= 1e-5 * scale + 1e-6), np.abs(o[:, :c] - gold).max()
+        outs[order] = o
+    assert np.allclose(outs[FLEX_AXW_A_XW], outs[FLEX_AXW_AX_W], rtol=1e-3, atol=1e-3)
+    auto = h.run(Xd, Wd).cpu().numpy()
+    assert np.array_equal(auto, outs[FLEX_AXW_A_XW if h.ld <= dim else FLEX_AXW_AX_W])
+    h.destroy()
