@@ -358,6 +358,9 @@ __global__ __launch_bounds__(64 * WPB) void spmm_flat_kernel(PlanView p, const f
         log[4] = 1;
         log[5] = blockIdx.x % kXcds;
         for (int i = 0; i < 5; ++i) log[6 + i] = phase[i];
+        uint32_t hw_id;  // wave / SIMD / CU / SH / SE the wave ran on (≙ the reference's per-SM timing, flex.cu:27-79)
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        log[11] = hw_id;
     }
 #else
     // A chunk holds at most 63 tasks (planner invariant): all descriptors come with one coalesced

@@ -61,6 +61,19 @@ def main():
     print(f" live waves per {step:.1f}us bucket:", live)
     life = (t1 - t0) * tick
     print(" wave life us: mean %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f" % (life.mean(), *np.percentile(life, [50, 90, 99, 100])))
+    # per-CU table (≙ the reference's per-SM timing, flex.cu:27-79, 5087-5126): HW_ID = wave[3:0] simd[5:4] cu[11:8] sh[12] se[14:13]
+    hw = t[:, 11]
+    cu_key = xcc * 4096 + ((hw >> 13) & 3) * 1024 + ((hw >> 12) & 1) * 512 + ((hw >> 8) & 15)
+    keys = np.unique(cu_key)
+    busy_us = np.array([life[cu_key == kk].sum() for kk in keys])
+    recs_cu = np.array([nrec[cu_key == kk].sum() for kk in keys])
+    last_cu = np.array([((t1[cu_key == kk].max() - base) * tick) for kk in keys])
+    print(f" CUs seen: {len(keys)}; wave-time per CU us: min {busy_us.min():.0f} mean {busy_us.mean():.0f} max {busy_us.max():.0f} "
+          f"({100 * busy_us.max() / busy_us.mean() - 100:.0f}% imb); records per CU: min {recs_cu.min()} mean {recs_cu.mean():.0f} "
+          f"max {recs_cu.max()} ({100 * recs_cu.max() / recs_cu.mean() - 100:.0f}% imb); last exit per CU us: "
+          f"min {last_cu.min():.1f} mean {last_cu.mean():.1f} max {last_cu.max():.1f}")
+    per_xcc = [int(np.sum((keys // 4096) == x)) for x in range(8)]
+    print(f" CUs per XCC: {per_xcc}")
     busy = t[nch > 0]
     ex = (busy[:, 2] - base) * tick
     print(" exit time of busy waves us: p1 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f" % tuple(np.percentile(ex, [1, 50, 90, 99, 100])))
