@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--shuffle", type=int, default=1, help="0: keep the generator's planted order (locality upper bound)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + FLEX_BENCH_DEVICE=0 rehearses the N>1 path on a one-GPU box (not a measurement)")
+    ap.add_argument("--bcast", default="broadcast", choices=["broadcast", "scatter_allgather"],
+                    help="how B reaches the other ranks (untimed, reported as b_bcast_ms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-copy-probe", action="store_true", help="skip the streaming read / copy probe that measures achievable HBM GB/s")
     ap.add_argument("--no-vendor", action="store_true", help="skip the hipSPARSE side-by-side (N=1 only)")
@@ -108,10 +110,10 @@ def main():
         dist.barrier()
         t0 = time.perf_counter()
         if args.backend == "nccl":
-            flex_amd.broadcast_dense(B, src=0)  # RCCL over xGMI
+            flex_amd.broadcast_dense(B, src=0, method=args.bcast)  # RCCL over xGMI
         else:
             Bh = B.cpu()
-            flex_amd.broadcast_dense(Bh, src=0)
+            flex_amd.broadcast_dense(Bh, src=0, method=args.bcast)
             B.copy_(Bh)
         torch.cuda.synchronize()
         bcast_ms = (time.perf_counter() - t0) * 1e3

@@ -66,9 +66,37 @@ def make_shard(a: "_b.HostCsr", k: int, rank: int, world: int, order: str = "clu
     return RowShard(ap, vo, bounds, rank, world)
 
 
-def broadcast_dense(B, src: int = 0):
-    """One broadcast of the dense operand; `nccl` (RCCL over xGMI) on GPUs, `gloo` in CPU tests."""
+def broadcast_dense(B, src: int = 0, method: str = "broadcast"):
+    """B (same-shaped tensor on every rank; contents valid on `src`) becomes valid everywhere.
+
+    "broadcast" (default): one collective broadcast.  "scatter_allgather": the source scatters W equal row
+    slices, one to each rank, and an all-gather completes every copy -- on xGMI, which is point-to-point,
+    the source then feeds all of its links at once and every other link carries a slice, where a ring
+    broadcast is paced by a single link (804 MB over 7 links vs 1).  Rows that do not divide
+    by the world size go through a zero-padded staging tensor.  `nccl` (= RCCL) on GPUs, `gloo` in CPU tests.
+    The second form is covered by 3-rank gloo tests only (no multi-GPU box this round), hence not the default."""
+    import torch
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return B
+    if method == "broadcast":
         dist.broadcast(B, src=src)
+        return B
+    if method != "scatter_allgather":
+        raise ValueError(method)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = B.shape[0]
+    per = -(-n // world)
+    row_elems = B[0].numel() if n else 0
+    full = torch.empty((world * per,) + tuple(B.shape[1:]), dtype=B.dtype, device=B.device) if world * per != n else B
+    if full is not B and rank == src:
+        full[:n].copy_(B)
+        full[n:].zero_()
+    mine = torch.empty((per,) + tuple(B.shape[1:]), dtype=B.dtype, device=B.device)
+    if per * row_elems:
+        parts = list(full.split(per, dim=0)) if rank == src else None
+        dist.scatter(mine, scatter_list=parts, src=src)
+        dist.all_gather_into_tensor(full, mine)
+    if full is not B:
+        B.copy_(full[:n])
     return B

@@ -101,3 +101,48 @@ def test_shard_local_csr_uses_original_columns():
             rp, cols, vals = sh.local_csr()
             got[sh.original_rows()] = oracle.spmm(rp, cols, vals, B)
         assert oracle.rescheck(gold, got, a.rowPtr)[0] == 0
+
+
+BCAST_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+import flex_amd
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+ok = True
+for shape in ((1001, 5), (999, 8), (3, 4), (1, 2), (0, 4)):   # rows that do and do not divide by 3, fewer rows than ranks, none
+    for method in ("scatter_allgather", "broadcast"):
+        for src in (0, 2):
+            ref = torch.from_numpy(np.random.default_rng(hash((shape, src)) %% 1000).uniform(-1, 1, shape).astype(np.float32))
+            B = ref.clone() if rank == src else torch.full(shape, 7.0)
+            flex_amd.broadcast_dense(B, src=src, method=method)
+            ok = ok and bool(torch.equal(B, ref))
+flags = [None] * world
+dist.all_gather_object(flags, ok)
+if rank == 0:
+    open(sys.argv[1], "w").write("ok" if all(flags) else "bad")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_three_rank_broadcast_of_the_dense_operand(tmp_path):
+    """broadcast_dense: scatter + all-gather (the xGMI-friendly form) and the plain broadcast deliver the
+    same bytes for every shape, from any source."""
+    pytest.importorskip("torch")
+    world = 3
+    out = str(tmp_path / "bcast.txt")
+    script = tmp_path / "bcast_worker.py"
+    script.write_text(BCAST_WORKER % {"root": ROOT})
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, str(script), out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        log, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, log
+    assert open(out).read() == "ok"
