@@ -4,14 +4,23 @@ import collections
 import csv
 import glob
 import json
+import re
 import sys
 
 out = sys.argv[1]
+
+
+def kname(full):
+    """'void flex::(anonymous namespace)::spmm_flat_kernel<16, true, 4, 4>(flex::PlanView, ...)' -> 'spmm_flat_kernel<16, true, 4, 4>'"""
+    m = re.search(r"flex::(?:\(anonymous namespace\)::)?(\w+(?:<[^>]*>)?)", full)
+    return m.group(1) if m else full
+
+
 res = {}
 for f in glob.glob(f"{out}/kt/*/*_kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         if "flex::" in r["Name"]:
-            name = r["Name"].split("(")[0].split("::")[-1] if "<" not in r["Name"] else r["Name"].split("::")[-1].split("(")[0]
+            name = kname(r["Name"])
             res.setdefault(name, {})["calls"] = int(r["Calls"])
             res[name]["avg_us"] = float(r["AverageNs"]) / 1e3
 for d in ("pmc1", "pmc2", "pmc3"):
@@ -19,7 +28,7 @@ for d in ("pmc1", "pmc2", "pmc3"):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             if "flex::" in r["Kernel_Name"]:
-                name = r["Kernel_Name"].split("::")[-1].split("(")[0]
+                name = kname(r["Kernel_Name"])
                 agg[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
         for (name, c), v in agg.items():
             res.setdefault(name, {})[c] = sum(v) / len(v)
@@ -38,7 +47,7 @@ try:
         if line.startswith("{") and '"config"' in line:
             cfg = json.loads(line)["config"]
     for name, d in res.items():
-        if cfg and "fetch_MB_x2" in d:
+        if cfg and "fetch_MB_x2" in d and name.startswith("spmm_"):
             nnz, n, k = cfg["nnz"], cfg["n"], cfg["k"]
             d["u_l2"] = 4.0 * nnz * k / max(1.0, d["fetch_MB_x2"] * 1e6 - 8.0 * nnz - 4.0 * (n + 1))
 except (OSError, KeyError, ValueError):
