@@ -193,6 +193,9 @@ def main():
                 "b_reuse_wave": round(st["reuse_wave"], 3), "b_reuse_xcd": round(st["reuse_xcd"], 3),
                 "chunk_imb_pct": round(st["chunk_imb_pct"], 1), "xcd_imb_pct": round(st["xcd_imb_pct"], 2),
                 "split_nnz_pct": round(st["split_nnz_pct"], 2), "pad_pct": round(st["pad_pct"], 2)})
+            # bytes the launch must move if every XCD (private L2) fetches each B row it needs exactly once:
+            # the floor of a row-partitioned schedule on this chip, between `algorithmic_bytes_per_launch` and `traffic`
+            out["roofline"]["private_l2_model_bytes"] = int(st["l2_bytes"])
         if world == 1 and not args.no_copy_probe:
             # achievable HBM bandwidth on this box, measured by the library's own streaming kernels
             pr = flex_amd.hbm_probe(local_rank, mib=2048, reps=10)

@@ -29,8 +29,6 @@
 //    pieces go to k-wide partial slots instead and are summed, in a fixed order,
 //    by whichever piece finishes last, inside the same launch (deterministic; the
 //    reference uses atomicAdd for its split rows, mat.cu:816-824).
-#include <cstdlib>
-
 #include "internal.h"
 
 namespace flex {
@@ -499,10 +497,9 @@ int launch_spmm(const PlanView &v, int lanes_per_nz, bool off32, bool vec4, cons
         FLEX_HIP_TRY(hipGetLastError());
         return FLEX_OK;
     }
-    static const bool u8 = [] { const char *e = std::getenv("FLEX_U8"); return e && *e == '1'; }();  // tuning experiments
-    switch (lanes_per_nz) {
-        case 8: return u8 ? launch_v4_off<8, 8>(v, off32, dB, dC, s) : launch_v4_off<8, 4>(v, off32, dB, dC, s);
-        case 16: return u8 ? launch_v4_off<16, 8>(v, off32, dB, dC, s) : launch_v4_off<16, 4>(v, off32, dB, dC, s);
+    switch (lanes_per_nz) {  // U: 4 KiB in flight per wave on the narrow tiles, 8 KiB on the wide ones (U=8 on G<=16 measured the same)
+        case 8: return launch_v4_off<8, 4>(v, off32, dB, dC, s);
+        case 16: return launch_v4_off<16, 4>(v, off32, dB, dC, s);
         case 32: return launch_v4_off<32, 8>(v, off32, dB, dC, s);
         case 64: return launch_v4_off<64, 8>(v, off32, dB, dC, s);
         default: return FLEX_ERR_UNSUPPORTED;
