@@ -69,7 +69,7 @@ class _SynthParams(C.Structure):  # flex_synth_params
 
 # every symbol include/flex_spmm.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = [
-    "flex_plan_create", "flex_plan_create_mapped", "flex_plan_create_rows", "flex_spmm",
+    "flex_plan_create", "flex_plan_create_ld", "flex_plan_create_mapped", "flex_plan_create_rows", "flex_spmm",
     "flex_plan_destroy", "flex_plan_get_info", "flex_plan_get_stats", "flex_hbm_probe", "flex_gather_rows", "flex_csv_load", "flex_mtx_load",
     "flex_csv_save", "flex_csr_save_bin", "flex_csr_load_bin", "flex_csr_fingerprint", "flex_perm_save", "flex_perm_load",
     "flex_host_csr_free", "flex_fill_dense_rand", "flex_order_rcm", "flex_order_cluster", "flex_order_gorder", "flex_perm_csr",
@@ -109,6 +109,7 @@ def lib():
         L = C.CDLL(_SO)
         vp, i64, i32, u32 = C.c_void_p, C.c_int64, C.c_int, C.c_uint
         L.flex_plan_create.argtypes = [C.POINTER(vp), C.POINTER(_Csr), i32, i32, u32]
+        L.flex_plan_create_ld.argtypes = [C.POINTER(vp), C.POINTER(_Csr), i32, i32, i32, i32, u32]
         L.flex_plan_create_mapped.argtypes = [C.POINTER(vp), C.POINTER(_Csr), vp, i32, i32, u32]
         L.flex_plan_create_rows.argtypes = [C.POINTER(vp), C.POINTER(_Csr), i64, i64, vp, i32, i32, u32]
         L.flex_spmm.argtypes = [vp, vp, vp, vp]
@@ -326,7 +327,7 @@ class Plan:
     """flex_plan handle (≙ Mat after csr2_DiagTiling + alpha_transfer)."""
 
     def __init__(self, a: HostCsr, k: int, device: int = 0, order: int = FLEX_ORDER_NATURAL,
-                 vo_mp=None, rows=None, col_map=None):
+                 vo_mp=None, rows=None, col_map=None, ldb: int | None = None, ldc: int | None = None):
         self._h = C.c_void_p()
         self._keep = (a, vo_mp, col_map)
         v = a.view()
@@ -339,6 +340,8 @@ class Plan:
         elif vo_mp is not None:
             vm = np.ascontiguousarray(vo_mp, dtype=np.int32)
             rc = L.flex_plan_create_mapped(C.byref(self._h), C.byref(v), vm.ctypes.data, k, device, order)
+        elif ldb is not None or ldc is not None:
+            rc = L.flex_plan_create_ld(C.byref(self._h), C.byref(v), k, ldb or k, ldc or k, device, order)
         else:
             rc = L.flex_plan_create(C.byref(self._h), C.byref(v), k, device, order)
         _check(rc, "flex_plan_create")

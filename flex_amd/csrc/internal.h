@@ -28,6 +28,7 @@ struct PlanView {
     uint32_t fused_fixup;    // 1: the last piece to finish sums the row inside the launch; 0: spmm_fixup_kernel does
     uint32_t n_chunks;
     int32_t k;
+    int32_t ldb, ldc;        // floats between consecutive rows of B and of C (>= k; == k for dense operands)
     uint32_t xcd_remap;      // 1: remap workgroup ids so each XCD walks one contiguous slice of the schedule
     uint32_t lds_extra;      // bytes of unused dynamic LDS per workgroup (occupancy throttle, tuning only)
     uint64_t *trace;         // diagnostic builds (-DFLEX_TRACE) only: 6 words per wave; nullptr otherwise
@@ -53,7 +54,7 @@ void note_hip_error(hipError_t e);
 // kernel launchers (spmm_kernels.hip)
 int launch_spmm(const PlanView &v, int lanes_per_nz, bool off32, bool vec4, const float *dB, float *dC,
                 hipStream_t s);
-int launch_fixup(const float *partial, const SplitRow *rows, uint32_t n_rows, int k, float *dC,
+int launch_fixup(const float *partial, const SplitRow *rows, uint32_t n_rows, int k, int ldc, float *dC,
                  hipStream_t s);
 int launch_gather_rows(float *dst, const float *src, const int32_t *idx, int64_t n, int k, hipStream_t s);
 

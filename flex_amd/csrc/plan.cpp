@@ -51,6 +51,7 @@ using namespace flex;
 
 struct flex_plan {
     int32_t m = 0, n = 0, k = 0, device = 0;
+    int32_t ldb = 0, ldc = 0;  // row strides of B and C in floats (== k unless flex_plan_create_ld)
     int64_t nnz = 0;
     int lanes_per_nz = 0;
     bool off32 = false;
@@ -106,7 +107,7 @@ void collect_stats(flex_plan *p, const std::vector<uint2> &rec, const std::vecto
     uint32_t nblk = (n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
     nblk = (nblk + kXcds - 1) / kXcds * kXcds;  // as launch_spmm cuts the grid
     const uint32_t cpx = std::max(1u, nblk / kXcds);
-    const uint32_t row_bytes32 = static_cast<uint32_t>(p->k) * 4u;
+    const uint32_t row_bytes32 = static_cast<uint32_t>(p->ldb) * 4u;
     std::vector<uint32_t> seen_wave(p->n, 0u), seen_wg(p->n, 0u), seen_xcd(p->n, 0u);
     int64_t xcd_rec[kXcds] = {0};
     for (uint32_t c = 0; c < n_chunks; ++c) {
@@ -170,7 +171,7 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
         if (avg_deg >= 128.0) G = std::min(G, 8);
     }
     p->lanes_per_nz = G;
-    p->off32 = static_cast<uint64_t>(A->n) * static_cast<uint64_t>(k) * 4u <= (uint64_t(1) << 32);
+    p->off32 = static_cast<uint64_t>(A->n) * static_cast<uint64_t>(p->ldb) * 4u <= (uint64_t(1) << 32);
 
     // schedule: sched[i] = row of A processed i-th
     std::vector<uint32_t> sched(m);
@@ -209,7 +210,7 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     uint32_t n_partials = 0;
     uint32_t wave_cost = 0;
     int64_t split_nnz = 0;
-    const uint32_t row_bytes32 = static_cast<uint32_t>(k) * 4u;
+    const uint32_t row_bytes32 = static_cast<uint32_t>(p->ldb) * 4u;
     auto emit_records = [&](uint32_t e0, uint32_t e1) {
         for (uint32_t e = e0; e < e1; ++e) {
             uint32_t c = A->col[e];
@@ -351,10 +352,14 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
 extern "C" {
 
 static int create_common(flex_plan **out, const flex_csr *hostA, int64_t row_begin, int64_t row_end,
-                         const int32_t *col_map, const int32_t *dst_map, int k, int device, unsigned flags) {
+                         const int32_t *col_map, const int32_t *dst_map, int k, int device, unsigned flags,
+                         int ldb = 0, int ldc = 0) {
     if (!out) return FLEX_ERR_INVALID;
     *out = nullptr;
     if (k <= 0 || device < 0) return FLEX_ERR_INVALID;
+    if (ldb == 0) ldb = k;
+    if (ldc == 0) ldc = k;
+    if (ldb < k || ldc < k) return FLEX_ERR_INVALID;
     const unsigned order = flags & FLEX_ORDER_MASK;
     if (order > FLEX_ORDER_GORDER || (flags & ~(FLEX_ORDER_MASK | FLEX_PLAN_STATS))) return FLEX_ERR_INVALID;
     int rc = validate_csr(hostA);
@@ -376,6 +381,8 @@ static int create_common(flex_plan **out, const flex_csr *hostA, int64_t row_beg
     p->m = static_cast<int32_t>(row_end - row_begin);
     p->n = hostA->n;
     p->k = k;
+    p->ldb = ldb;
+    p->ldc = ldc;
     p->nnz = static_cast<int64_t>(hostA->rowPtr[row_end]) - hostA->rowPtr[row_begin];
     p->device = device;
     rc = build_plan(p, hostA, static_cast<int32_t>(row_begin), static_cast<int32_t>(row_end), col_map, dst_map, flags);
@@ -395,6 +402,11 @@ int flex_plan_create(flex_plan **out, const flex_csr *hostA, int k, int device, 
     if (!hostA) return FLEX_ERR_INVALID;
     // dst_map == NULL means slice-local rows, which for the full range is the identity
     return create_common(out, hostA, 0, hostA->m, nullptr, nullptr, k, device, flags);
+}
+
+int flex_plan_create_ld(flex_plan **out, const flex_csr *hostA, int k, int ldb, int ldc, int device, unsigned flags) {
+    if (!hostA || ldb < k || ldc < k) return FLEX_ERR_INVALID;
+    return create_common(out, hostA, 0, hostA->m, nullptr, nullptr, k, device, flags, ldb, ldc);
 }
 
 int flex_plan_create_mapped(flex_plan **out, const flex_csr *hostA, const int32_t *vo_mp, int k, int device,
@@ -417,15 +429,15 @@ int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream) {
     int cur = -1;
     FLEX_HIP_TRY(hipGetDevice(&cur));
     if (cur != p->device) FLEX_HIP_TRY(hipSetDevice(p->device));
-    const bool vec4 = (p->k % 4 == 0) &&
+    const bool vec4 = (p->k % 4 == 0) && (p->ldb % 4 == 0) && (p->ldc % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(dB) | reinterpret_cast<uintptr_t>(dC)) % 16 == 0);
     const bool fused = vec4 && p->fused_fixup;  // the generic kernel always leaves the sum to spmm_fixup_kernel
     PlanView v{p->d_rec, p->d_t_beg, p->d_t_dst, p->d_chunk, p->d_partial, p->d_piece_row, p->d_split, p->d_split_cnt,
-               p->partial_bytes, fused ? 1u : 0u, p->n_slots, p->k,
+               p->partial_bytes, fused ? 1u : 0u, p->n_slots, p->k, p->ldb, p->ldc,
                p->xcd_remap ? 1u : 0u, p->lds_extra, p->trace};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc = launch_spmm(v, p->lanes_per_nz, p->off32, vec4, dB, dC, s);
-    if (rc == FLEX_OK && !fused) rc = launch_fixup(p->d_partial, p->d_split, p->n_split, p->k, dC, s);
+    if (rc == FLEX_OK && !fused) rc = launch_fixup(p->d_partial, p->d_split, p->n_split, p->k, p->ldc, dC, s);
     if (cur != p->device) (void)hipSetDevice(cur);
     return rc;
 }

@@ -134,8 +134,11 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
     constexpr int S = 64 / G;
     const int slot = lane / G;
     const int k = p.k;
-    const uint32_t lane_off = (col_ok ? c0 : 0) * 4u;
-    const uint64_t row_bytes = static_cast<uint64_t>(k) * 4u;
+    const uint64_t ldc = static_cast<uint64_t>(p.ldc);
+    // lanes past column k gather the tile's FIRST column instead: a line this record's gather touches anyway
+    // (column 0 of the row would add a cache line per record to the last tile of a k that is not a multiple of 4G)
+    const uint32_t lane_off = (col_ok ? c0 : c0 - (lane % G) * 4) * 4u;
+    const uint64_t row_bytes = static_cast<uint64_t>(p.ldb) * 4u;
     const uint2 *__restrict__ rec = p.rec;
 
     const uint32_t nt = hdr.y, zb = hdr.z, ze = hdr.w;
@@ -181,7 +184,7 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
                 if (slot == 0 && col_ok) {
 #endif
                     const v4f val = {r.x, r.y, r.z, r.w};
-                    __builtin_nontemporal_store(val, reinterpret_cast<v4f *>(C + static_cast<uint64_t>(dst) * k + c0));
+                    __builtin_nontemporal_store(val, reinterpret_cast<v4f *>(C + static_cast<uint64_t>(dst) * ldc + c0));
                 }
             } else {
                 // a piece of a split row is a chunk of its own (planner invariant): remember its sum and
@@ -310,7 +313,7 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
                         }
                     }
                     const v4f val = {s4.x, s4.y, s4.z, s4.w};
-                    __builtin_nontemporal_store(val, reinterpret_cast<v4f *>(C + static_cast<uint64_t>(sr.row) * k + c0));
+                    __builtin_nontemporal_store(val, reinterpret_cast<v4f *>(C + static_cast<uint64_t>(sr.row) * ldc + c0));
                 }
                 if (lane == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(256) void spmm_generic_kernel(PlanView p, const flo
             const uint2 r = rec[z];
             const float v = as_f32(r.y);
             const float *brow = OFF32 ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + r.x)
-                                      : B + static_cast<uint64_t>(r.x) * k;
+                                      : B + static_cast<uint64_t>(r.x) * p.ldb;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int c = cb + 64 * i;
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(256) void spmm_generic_kernel(PlanView p, const flo
             }
         }
         float *orow = (dst & kPartialFlag) ? p.partial + static_cast<uint64_t>(dst & ~kPartialFlag) * k
-                                           : C + static_cast<uint64_t>(dst) * k;
+                                           : C + static_cast<uint64_t>(dst) * p.ldc;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = cb + 64 * i;
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(256) void spmm_generic_kernel(PlanView p, const flo
 // one per piece; the adds stay strictly in piece order, so the result is reproducible.
 __global__ __launch_bounds__(256) void spmm_fixup_kernel(const float *__restrict__ partial,
                                                          const SplitRow *__restrict__ rows, uint32_t n_rows,
-                                                         int k, float *__restrict__ C) {
+                                                         int k, int ldc, float *__restrict__ C) {
     const int lane = threadIdx.x & 63;
     const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t i = blockIdx.x * kWavesPerBlock + wib;
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(256) void spmm_fixup_kernel(const float *__restrict
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if (j + u < sr.count) s += v[u];
-        C[static_cast<uint64_t>(sr.row) * k + c] = s;
+        C[static_cast<uint64_t>(sr.row) * ldc + c] = s;
     }
 }
 
@@ -506,10 +509,10 @@ int launch_spmm(const PlanView &v, int lanes_per_nz, bool off32, bool vec4, cons
     }
 }
 
-int launch_fixup(const float *partial, const SplitRow *rows, uint32_t n_rows, int k, float *dC, hipStream_t s) {
+int launch_fixup(const float *partial, const SplitRow *rows, uint32_t n_rows, int k, int ldc, float *dC, hipStream_t s) {
     if (n_rows == 0) return FLEX_OK;
     const uint32_t nblk = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
-    hipLaunchKernelGGL(spmm_fixup_kernel, dim3(nblk), dim3(256), 0, s, partial, rows, n_rows, k, dC);
+    hipLaunchKernelGGL(spmm_fixup_kernel, dim3(nblk), dim3(256), 0, s, partial, rows, n_rows, k, ldc, dC);
     FLEX_HIP_TRY(hipGetLastError());
     return FLEX_OK;
 }

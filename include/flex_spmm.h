@@ -69,6 +69,13 @@ typedef struct flex_plan flex_plan;
  * pillar tiler is replaced by an nnz-balanced wave/row-panel planner. */
 int flex_plan_create(flex_plan **out, const flex_csr *hostA, int k, int device, unsigned flags);
 
+/* Same with strided dense operands: row r of B starts at dB + r*ldb, row r of C at dC + r*ldc (floats,
+ * ldb >= k, ldc >= k); the ldc-k trailing floats of every C row are left untouched.  For callers whose
+ * feature width is not a multiple of 32: a B row that is not a whole number of 128-byte cache lines costs
+ * every gather an extra line (k=100 runs 50 % slower than k=128 on the reddit shape), so store k=100 with
+ * ldb = ldc = 128.  No reference counterpart (the reference runs k = 32 and 128 only). */
+int flex_plan_create_ld(flex_plan **out, const flex_csr *hostA, int k, int ldb, int ldc, int device, unsigned flags);
+
 /* Same, for a CSR that a reordered loader already permuted (DataLoaderRcm &c.,
  * DataLoader.cu:723-857): row r' of hostA is original row vo_mp[r'] and column c' is
  * original column vo_mp[c'].  The plan folds both maps in at build time, so flex_spmm

@@ -494,3 +494,25 @@ def test_axw_both_orders_match_a_float64_reference(dim, c):
     auto = h.run(Xd, Wd).cpu().numpy()
     assert np.array_equal(auto, outs[FLEX_AXW_A_XW if h.ld <= dim else FLEX_AXW_AX_W])
     h.destroy()
+
+
+@pytest.mark.parametrize("k,ldb,ldc", [(100, 128, 128), (100, 100, 128), (12, 20, 16), (7, 9, 11), (128, 160, 128), (260, 288, 264)])
+def test_strided_dense_operands(k, ldb, ldc):
+    """flex_plan_create_ld: rows of B / C start every ldb / ldc floats; columns >= k of B are never read into
+    the result and the tail of every C row is left untouched (vector and generic kernels, split rows included)."""
+    import torch
+    a = random_csr(2000, 2000, 14, seed=41, long_rows={2: 1900, 17: 600})
+    rng = np.random.default_rng(8)
+    Bs = rng.uniform(-1, 1, size=(a.n, ldb)).astype(np.float32)
+    Bs[:, k:] = np.nan  # poison: anything read from the padding would surface
+    p = Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER, ldb=ldb, ldc=ldc)
+    Bd = torch.from_numpy(Bs).cuda()
+    Cd = torch.full((a.m, ldc), -7.0, dtype=torch.float32, device="cuda")
+    for _ in range(2):
+        p.spmm(Bd.data_ptr(), Cd.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    Cs = Cd.cpu().numpy()
+    assert np.all(Cs[:, k:] == -7.0)
+    assert_matches_oracle(a, np.ascontiguousarray(Bs[:, :k]), np.ascontiguousarray(Cs[:, :k]))
+    with pytest.raises(flex_amd.FlexError):
+        Plan(a, k, ldb=k - 1)
