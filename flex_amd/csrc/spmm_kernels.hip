@@ -121,11 +121,10 @@ __device__ __forceinline__ void stage_window(uint2 *my_lds, const uint2 *__restr
 }
 
 // All the work of one chunk once its header {first task, #tasks, first record, end record} and its
-// task descriptors (lane i: t_beg[t0+i], t_dst[t0+i]) are in registers.  `staged`: the first
-// window of records is already in my_lds (for callers that prefetch it; unused today).
+// task descriptors (lane i: t_beg[t0+i], t_dst[t0+i]) are in registers.
 template <int G, bool OFF32, int U>
 __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint32_t my_beg, uint32_t my_dst,
-                                              bool staged, uint2 *my_lds, const char *__restrict__ Bb,
+                                              uint2 *my_lds, const char *__restrict__ Bb,
                                               float *__restrict__ C, int lane, int c0, bool col_ok
 #ifdef FLEX_TRACE
                                               , uint64_t *phase, uint64_t &last_
@@ -204,7 +203,7 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
     for (uint32_t wz = zb; wz < ze; wz += kWindowRecs) {
         const uint32_t wn = min(static_cast<uint32_t>(kWindowRecs), ze - wz);
         // stage this window's records: coalesced 512-B loads, one ds_write_b64 per lane and load
-        if (!(staged && wz == zb)) stage_window(my_lds, rec, wz, wn, lane);
+        stage_window(my_lds, rec, wz, wn, lane);
         FLEX_STAMP(1);  // records -> LDS
 #ifdef FLEX_ABL_STAGEONLY  // timing-only ablation: header, descriptors and records fetched, then leave
         if (p.k > 0) {
@@ -349,7 +348,7 @@ __global__ __launch_bounds__(64 * WPB) void spmm_flat_kernel(PlanView p, const f
     const uint4 hdr = p.chunk[chunk];
     const uint32_t my_beg = (static_cast<uint32_t>(lane) <= hdr.y) ? p.t_beg[hdr.x + lane] : 0u;
     const uint32_t my_dst = (static_cast<uint32_t>(lane) < hdr.y) ? p.t_dst[hdr.x + lane] : 0u;
-    compute_chunk<G, OFF32, U>(p, hdr, my_beg, my_dst, false, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok, phase, last_);
+    compute_chunk<G, OFF32, U>(p, hdr, my_beg, my_dst, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok, phase, last_);
     if (lane == 0 && p.trace != nullptr) {
         uint64_t *log = p.trace + static_cast<uint64_t>(chunk) * 12;
         log[0] = xcc_id();
@@ -371,7 +370,7 @@ __global__ __launch_bounds__(64 * WPB) void spmm_flat_kernel(PlanView p, const f
     if (hdr.y == 0) return;  // an empty entry that pads this XCD's slice of the table (plan.cpp)
     const uint32_t my_beg = (static_cast<uint32_t>(lane) <= hdr.y) ? p.t_beg[hdr.x + lane] : 0u;
     const uint32_t my_dst = (static_cast<uint32_t>(lane) < hdr.y) ? p.t_dst[hdr.x + lane] : 0u;
-    compute_chunk<G, OFF32, U>(p, hdr, my_beg, my_dst, false, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok);
+    compute_chunk<G, OFF32, U>(p, hdr, my_beg, my_dst, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok);
 #endif
 }
 

@@ -12,7 +12,7 @@ for d in ("sq1","sq2"):
     for f in glob.glob("$out/%s/*/*_counter_collection.csv" % d):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "spmm_flat" in r["Kernel_Name"] or "spmm_stream" in r["Kernel_Name"]:
+            if "spmm_flat" in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for c, v in sorted(agg.items()):
             print(f"{c:24s} {sum(v)/len(v):14.0f}")

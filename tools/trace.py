@@ -51,7 +51,7 @@ def main():
     print(" chunks per wave: mean %.2f max %d; waves with 0 chunks: %d" % (nch.mean(), nch.max(), (nch == 0).sum()))
     ph = t[:, 6:11].sum(axis=0) * tick
     tot = ((t1 - t0) * tick).sum()
-    names = ["descriptors", "records->LDS", "gather wait", "fma+flush", "ticketing"]
+    names = ["descriptors", "records->LDS", "gather wait", "fma+flush", "(unused)"]
     print(" wave-time shares (stamped build, waits drained at every stamp): " +
           ", ".join(f"{n} {100*v/tot:.1f}%" for n, v in zip(names, ph)) + f"; total {tot/len(t):.1f} us/wave")
     span = (t1.max() - base) * tick
