@@ -516,3 +516,42 @@ def test_strided_dense_operands(k, ldb, ldc):
     assert_matches_oracle(a, np.ascontiguousarray(Bs[:, :k]), np.ascontiguousarray(Cs[:, :k]))
     with pytest.raises(flex_amd.FlexError):
         Plan(a, k, ldb=k - 1)
+
+
+def test_seeded_fuzz_over_shapes_degrees_widths_schedules():
+    """250 seeded random cases through the planner's every branch at small sizes: rectangular and square
+    shapes, empty rows / empty matrices, degrees on both sides of the column-tile thresholds, rows long
+    enough to split (in-launch reduction across k-tiles), every k class (vector, generic, multi-tile),
+    every schedule, strided operands -- each checked with the reference's resCheck against the oracle."""
+    import torch
+    rng = np.random.default_rng(20251004)
+    orders = [FLEX_ORDER_NATURAL, FLEX_ORDER_RCM, flex_amd.FLEX_ORDER_CLUSTER]
+    for case in range(250):
+        m = int(rng.choice([1, 2, 7, 63, 64, 65, 300, 1500, 4000, 20000]))
+        square = bool(rng.integers(0, 2)) or m < 3
+        n = m if square else int(rng.choice([1, 5, 97, 1000, 5000]))
+        avg = float(rng.choice([0.0, 0.5, 3, 12, 30, 140]))
+        long_rows = {}
+        if m >= 300 and rng.integers(0, 2):
+            long_rows = {int(rng.integers(0, m)): int(min(n, rng.integers(200, 3000))) for _ in range(int(rng.integers(1, 4)))}
+        a = random_csr(m, n, min(avg, n), seed=1000 + case, long_rows=long_rows, empty_frac=float(rng.choice([0.0, 0.1, 0.6])),
+                       sorted_cols=bool(rng.integers(0, 2)))
+        k = int(rng.choice([1, 4, 5, 8, 32, 36, 64, 100, 128, 132, 256, 300]))
+        order = int(rng.choice(orders)) if square else FLEX_ORDER_NATURAL
+        strided = bool(rng.integers(0, 3) == 0)
+        ldb = k + int(rng.choice([0, 4, 28])) if strided else k
+        ldc = k + int(rng.choice([0, 4, 28])) if strided else k
+        B = rng.uniform(-1, 1, size=(n, ldb)).astype(np.float32)
+        p = Plan(a, k, order=order | flex_amd.FLEX_PLAN_STATS, ldb=ldb, ldc=ldc) if strided else Plan(a, k, order=order | flex_amd.FLEX_PLAN_STATS)
+        Cd = torch.full((m, ldc), 3.5, dtype=torch.float32, device="cuda")
+        p.spmm(torch.from_numpy(B).cuda().data_ptr(), Cd.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        C = Cd.cpu().numpy()
+        tag = f"case {case}: m={m} n={n} avg={avg} k={k} order={order} ld=({ldb},{ldc}) long={long_rows}"
+        assert np.all(C[:, k:] == 3.5), tag
+        gold = oracle.spmm(a.rowPtr, a.col, a.vals, np.ascontiguousarray(B[:, :k]), nthreads=4)
+        cnt, max_err, me_nnz, _ = oracle.rescheck(gold, np.ascontiguousarray(C[:, :k]), a.rowPtr)
+        assert cnt == 0, f"{tag}: {cnt} mismatches, max err {max_err:g} on a row of {me_nnz} nnz"
+        st, info = p.stats(), p.info()
+        assert st["records"] >= a.nnz and info["n_slots"] >= info["n_chunks"] and info["nnz"] == a.nnz, tag
+        p.destroy()
