@@ -192,8 +192,11 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     // high-degree graphs (reddit: best at >= 256).  Measured on MI355X, DESIGN.md 3.3.
     // (k <= 32, G = 8: a step consumes 8 records, so the same number of steps needs more records per chunk --
     //  flickr k=32 best at 192, ppi 192, yelp 256, pubmed 128; 7-23 % over the k=128 rule)
-    const long auto_budget = G <= 8 ? std::clamp<long>(static_cast<long>(16.0 * avg_deg), 128, 256)
-                                    : std::clamp<long>(static_cast<long>(8.0 * avg_deg), 96, 256);
+    const long lo_budget = G <= 8 ? 128 : 96;
+    long auto_budget = std::clamp<long>(static_cast<long>((G <= 8 ? 16.0 : 8.0) * avg_deg), lo_budget, 256);
+    // small inputs: keep at least ~2048 chunks (two waves per SIMD) before growing them (wiki-Vote shape, k=32:
+    // 5.5 us at 128-160 records per chunk, 6.3 at 200)
+    auto_budget = std::min(auto_budget, std::max<long>(lo_budget, static_cast<long>(A->rowPtr[r1] - A->rowPtr[r0]) / 2048));
     const uint32_t wave_nnz = static_cast<uint32_t>(env_long("FLEX_WAVE_NNZ", auto_budget));
     const uint32_t row_cost = static_cast<uint32_t>(env_long("FLEX_ROW_COST", 16));
     p->xcd_remap = env_long("FLEX_XCD_REMAP", 1) != 2;  // 2 = off (tuning experiments only)
