@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstring>
 #include <numeric>
+#include <stdexcept>
 #include <vector>
 
 #include "internal.h"
@@ -172,7 +173,7 @@ int order_cluster_host(int64_t n, const uint32_t *rowPtr, const uint32_t *col, s
 
 }  // namespace flex
 
-extern "C" int flex_order_cluster(const flex_csr *A, uint32_t *rank) {
+extern "C" int flex_order_cluster(const flex_csr *A, uint32_t *rank) try {
     if (!rank) return FLEX_ERR_INVALID;
     int rc = flex::validate_csr(A);
     if (rc) return rc;
@@ -182,4 +183,10 @@ extern "C" int flex_order_cluster(const flex_csr *A, uint32_t *rank) {
     if (rc) return rc;
     std::copy(r.begin(), r.end(), rank);
     return FLEX_OK;
+} catch (const std::bad_alloc &) {
+    return FLEX_ERR_NOMEM;
+} catch (const std::length_error &) {
+    return FLEX_ERR_NOMEM;
+} catch (...) {  // nothing crosses the C ABI as an exception
+    return FLEX_ERR_INVALID;
 }

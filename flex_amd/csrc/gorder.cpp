@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <numeric>
+#include <stdexcept>
 #include <vector>
 
 #include "internal.h"
@@ -245,7 +246,7 @@ int order_gorder_host(int64_t n64, const uint32_t *rowPtr, const uint32_t *col, 
 
 }  // namespace flex
 
-extern "C" int flex_order_gorder(const flex_csr *A, uint32_t window, uint32_t *rank) {
+extern "C" int flex_order_gorder(const flex_csr *A, uint32_t window, uint32_t *rank) try {
     if (!rank || window == 0) return FLEX_ERR_INVALID;
     int rc = flex::validate_csr(A);
     if (rc) return rc;
@@ -255,4 +256,10 @@ extern "C" int flex_order_gorder(const flex_csr *A, uint32_t window, uint32_t *r
     if (rc) return rc;
     std::copy(r.begin(), r.end(), rank);
     return FLEX_OK;
+} catch (const std::bad_alloc &) {
+    return FLEX_ERR_NOMEM;
+} catch (const std::length_error &) {
+    return FLEX_ERR_NOMEM;
+} catch (...) {  // nothing crosses the C ABI as an exception
+    return FLEX_ERR_INVALID;
 }

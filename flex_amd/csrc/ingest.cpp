@@ -14,6 +14,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <stdexcept>
 #include <vector>
 
 #include "internal.h"
@@ -31,11 +32,12 @@ bool read_all(const char *path, std::vector<char> &buf) {
     const long sz = std::ftell(f);
     std::fseek(f, 0, SEEK_SET);
     if (sz < 0) { std::fclose(f); return false; }
-    buf.resize(static_cast<size_t>(sz) + 1);
+    buf.resize(static_cast<size_t>(sz) + 2);
     const size_t got = std::fread(buf.data(), 1, static_cast<size_t>(sz), f);
     std::fclose(f);
-    buf.resize(got + 1);
-    buf[got] = '\n';
+    buf.resize(got + 2);
+    buf[got] = '\n';      // the last line always ends
+    buf[got + 1] = '\0';  // and strto* never runs off the buffer (callers treat size()-1 as the end)
     return true;
 }
 
@@ -128,7 +130,7 @@ void flex_host_csr_free(flex_host_csr *a) {
     std::memset(a, 0, sizeof *a);
 }
 
-int flex_csv_load(const char *path, flex_host_csr *out) {
+int flex_csv_load(const char *path, flex_host_csr *out) try {
     if (!path || !out) return FLEX_ERR_INVALID;
     std::memset(out, 0, sizeof *out);
     std::vector<char> buf;
@@ -137,7 +139,7 @@ int flex_csv_load(const char *path, flex_host_csr *out) {
     if (auto s = name.find_last_of('/'); s != std::string::npos) name = name.substr(s + 1);
 
     Line ln[3];
-    const char *p = buf.data(), *end = buf.data() + buf.size();
+    const char *p = buf.data(), *end = buf.data() + buf.size() - 1;
     for (int i = 0; i < 3 && p < end; ++i) {
         const char *q = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
         ln[i].b = p;
@@ -203,6 +205,12 @@ int flex_csv_load(const char *path, flex_host_csr *out) {
     const int rc = graph_statistics(out);
     if (rc) flex_host_csr_free(out);
     return rc;
+} catch (const std::bad_alloc &) {
+    return FLEX_ERR_NOMEM;
+} catch (const std::length_error &) {
+    return FLEX_ERR_NOMEM;
+} catch (...) {  // nothing crosses the C ABI as an exception
+    return FLEX_ERR_INVALID;
 }
 
 // -------------------------------------------------------------------------------------------
@@ -233,12 +241,12 @@ static int finish_host_csr(flex_host_csr *out, int64_t m, int64_t n, std::vector
     return rc == FLEX_ERR_DUPLICATE ? FLEX_OK : rc;
 }
 
-int flex_mtx_load(const char *path, int sort_columns, flex_host_csr *out) {
+int flex_mtx_load(const char *path, int sort_columns, flex_host_csr *out) try {
     if (!path || !out) return FLEX_ERR_INVALID;
     std::memset(out, 0, sizeof *out);
     std::vector<char> buf;
     if (!read_all(path, buf)) return FLEX_ERR_IO;
-    const char *p = buf.data(), *end = buf.data() + buf.size();
+    const char *p = buf.data(), *end = buf.data() + buf.size() - 1;
     auto next_line = [&](Line &ln) {
         if (p >= end) return false;
         const char *q = static_cast<const char *>(std::memchr(p, '\n', static_cast<size_t>(end - p)));
@@ -266,6 +274,11 @@ int flex_mtx_load(const char *path, int sort_columns, flex_host_csr *out) {
         std::string sz(ln.b, ln.e);
         if (std::sscanf(sz.c_str(), "%lld %lld %lld", &m, &n, &nz) != 3 || m < 0 || n < 0 || nz < 0) return FLEX_ERR_FORMAT;
     }
+    if (m >= INT32_MAX || n >= INT32_MAX || nz >= (1ll << 32)) return FLEX_ERR_UNSUPPORTED;
+    // an entry line is at least "1 1\n": a header that promises more entries than the file can hold is refused
+    // before anything is allocated for it
+    if (nz > (end - p) / 4 + 1) return FLEX_ERR_FORMAT;
+    if (symmetric && 2 * nz >= (1ll << 32)) return FLEX_ERR_UNSUPPORTED;
     std::vector<uint32_t> ri(static_cast<size_t>(nz)), ci(static_cast<size_t>(nz));
     std::vector<float> vv(static_cast<size_t>(nz));
     for (long long i = 0; i < nz; ++i) {
@@ -276,12 +289,13 @@ int flex_mtx_load(const char *path, int sort_columns, flex_host_csr *out) {
         const long long r = std::strtoll(ln.b, &q, 10);
         const char *q2 = q;
         const long long c = std::strtoll(q2, &q, 10);
-        if (q == q2 || r < 1 || c < 1 || r > m || c > n) return FLEX_ERR_FORMAT;
+        // strto* skips newlines as white space: a number taken from beyond this line means the line is short
+        if (q == q2 || q > ln.e || r < 1 || c < 1 || r > m || c > n) return FLEX_ERR_FORMAT;
         double v = 1.0;  // pattern files carry no value (mtx2csr.cc:133-137)
         if (!pattern) {
             const char *q3 = q;
             v = std::strtod(q3, &q);  // complex: the real part is kept, the imaginary one read and dropped
-            if (q == q3) return FLEX_ERR_FORMAT;
+            if (q == q3 || q > ln.e) return FLEX_ERR_FORMAT;
             (void)cplx;
         }
         ri[i] = static_cast<uint32_t>(r - 1);
@@ -323,9 +337,15 @@ int flex_mtx_load(const char *path, int sort_columns, flex_host_csr *out) {
     std::string name(path);
     if (auto s = name.find_last_of('/'); s != std::string::npos) name = name.substr(s + 1);
     return finish_host_csr(out, m, n, rp, col, vals, name);
+} catch (const std::bad_alloc &) {
+    return FLEX_ERR_NOMEM;
+} catch (const std::length_error &) {
+    return FLEX_ERR_NOMEM;
+} catch (...) {  // nothing crosses the C ABI as an exception
+    return FLEX_ERR_INVALID;
 }
 
-int flex_csv_save(const char *path, const flex_csr *A) {
+int flex_csv_save(const char *path, const flex_csr *A) try {
     if (!path) return FLEX_ERR_INVALID;
     int rc = flex::validate_csr(A);
     if (rc) return rc;
@@ -338,11 +358,17 @@ int flex_csv_save(const char *path, const flex_csr *A) {
     for (int64_t i = 0; i < A->nnz; ++i) std::fprintf(f, i + 1 < A->nnz ? "%.9g," : "%.9g", static_cast<double>(A->vals[i]));
     std::fputc('\n', f);
     return std::fclose(f) == 0 ? FLEX_OK : FLEX_ERR_IO;
+} catch (const std::bad_alloc &) {
+    return FLEX_ERR_NOMEM;
+} catch (const std::length_error &) {
+    return FLEX_ERR_NOMEM;
+} catch (...) {  // nothing crosses the C ABI as an exception
+    return FLEX_ERR_INVALID;
 }
 
 static const char kBinMagic[8] = {'F', 'L', 'E', 'X', 'C', 'S', 'R', '1'};
 
-int flex_csr_save_bin(const char *path, const flex_csr *A) {
+int flex_csr_save_bin(const char *path, const flex_csr *A) try {
     if (!path) return FLEX_ERR_INVALID;
     int rc = flex::validate_csr(A);
     if (rc) return rc;
@@ -355,9 +381,15 @@ int flex_csr_save_bin(const char *path, const flex_csr *A) {
               std::fwrite(A->vals, sizeof(float), static_cast<size_t>(A->nnz), f) == static_cast<size_t>(A->nnz);
     ok = (std::fclose(f) == 0) && ok;
     return ok ? FLEX_OK : FLEX_ERR_IO;
+} catch (const std::bad_alloc &) {
+    return FLEX_ERR_NOMEM;
+} catch (const std::length_error &) {
+    return FLEX_ERR_NOMEM;
+} catch (...) {  // nothing crosses the C ABI as an exception
+    return FLEX_ERR_INVALID;
 }
 
-int flex_csr_load_bin(const char *path, flex_host_csr *out) {
+int flex_csr_load_bin(const char *path, flex_host_csr *out) try {
     if (!path || !out) return FLEX_ERR_INVALID;
     std::memset(out, 0, sizeof *out);
     FILE *f = std::fopen(path, "rb");
@@ -383,6 +415,12 @@ int flex_csr_load_bin(const char *path, flex_host_csr *out) {
     std::string name(path);
     if (auto s = name.find_last_of('/'); s != std::string::npos) name = name.substr(s + 1);
     return finish_host_csr(out, hdr[0], hdr[1], rp, col, vals, name);
+} catch (const std::bad_alloc &) {
+    return FLEX_ERR_NOMEM;
+} catch (const std::length_error &) {
+    return FLEX_ERR_NOMEM;
+} catch (...) {  // nothing crosses the C ABI as an exception
+    return FLEX_ERR_INVALID;
 }
 
 int flex_fill_dense_rand(float *hostB, int64_t n, int k) {
@@ -418,7 +456,7 @@ int flex_perm_save(const char *path, const uint32_t *rank, int64_t n, uint64_t f
     return ok ? FLEX_OK : FLEX_ERR_IO;
 }
 
-int flex_perm_load(const char *path, uint32_t *rank, int64_t n, uint64_t fingerprint) {
+int flex_perm_load(const char *path, uint32_t *rank, int64_t n, uint64_t fingerprint) try {
     if (!path || !rank || n < 0) return FLEX_ERR_INVALID;
     FILE *f = std::fopen(path, "rb");
     if (!f) return FLEX_ERR_IO;
@@ -439,6 +477,12 @@ int flex_perm_load(const char *path, uint32_t *rank, int64_t n, uint64_t fingerp
         return FLEX_ERR_NOMEM;
     }
     return FLEX_OK;
+} catch (const std::bad_alloc &) {
+    return FLEX_ERR_NOMEM;
+} catch (const std::length_error &) {
+    return FLEX_ERR_NOMEM;
+} catch (...) {  // nothing crosses the C ABI as an exception
+    return FLEX_ERR_INVALID;
 }
 
 }  // extern "C"

@@ -391,7 +391,13 @@ static int create_common(flex_plan **out, const flex_csr *hostA, int64_t row_beg
     p->ldc = ldc;
     p->nnz = static_cast<int64_t>(hostA->rowPtr[row_end]) - hostA->rowPtr[row_begin];
     p->device = device;
-    rc = build_plan(p, hostA, static_cast<int32_t>(row_begin), static_cast<int32_t>(row_end), col_map, dst_map, flags);
+    try {
+        rc = build_plan(p, hostA, static_cast<int32_t>(row_begin), static_cast<int32_t>(row_end), col_map, dst_map, flags);
+    } catch (const std::bad_alloc &) {  // nothing crosses the C ABI as an exception
+        rc = FLEX_ERR_NOMEM;
+    } catch (...) {
+        rc = FLEX_ERR_INVALID;
+    }
     if (rc == FLEX_OK && hipDeviceSynchronize() != hipSuccess) rc = FLEX_ERR_HIP;
     (void)hipSetDevice(prev);
     if (rc) {

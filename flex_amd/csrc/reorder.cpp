@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstring>
 #include <numeric>
+#include <stdexcept>
 #include <vector>
 
 #include "internal.h"
@@ -83,7 +84,7 @@ int order_rcm_host(int64_t n, const uint32_t *rowPtr, const uint32_t *col, std::
 
 extern "C" {
 
-int flex_order_rcm(const flex_csr *A, uint32_t *rank) {
+int flex_order_rcm(const flex_csr *A, uint32_t *rank) try {
     if (!rank) return FLEX_ERR_INVALID;
     int rc = flex::validate_csr(A);
     if (rc) return rc;
@@ -93,9 +94,15 @@ int flex_order_rcm(const flex_csr *A, uint32_t *rank) {
     if (rc) return rc;
     std::copy(r.begin(), r.end(), rank);
     return FLEX_OK;
+} catch (const std::bad_alloc &) {
+    return FLEX_ERR_NOMEM;
+} catch (const std::length_error &) {
+    return FLEX_ERR_NOMEM;
+} catch (...) {  // nothing crosses the C ABI as an exception
+    return FLEX_ERR_INVALID;
 }
 
-int flex_order_dfs(const flex_csr *A, uint32_t *rank) {
+int flex_order_dfs(const flex_csr *A, uint32_t *rank) try {
     // ≙ DataLoaderDFS (DataLoader.cu:324-395): pre-order numbering of an iterative depth-first search
     // that starts at vertex 0, follows out-edges in CSR order and restarts at the lowest unvisited vertex.
     if (!rank) return FLEX_ERR_INVALID;
@@ -123,9 +130,15 @@ int flex_order_dfs(const flex_csr *A, uint32_t *rank) {
         }
     }
     return FLEX_OK;
+} catch (const std::bad_alloc &) {
+    return FLEX_ERR_NOMEM;
+} catch (const std::length_error &) {
+    return FLEX_ERR_NOMEM;
+} catch (...) {  // nothing crosses the C ABI as an exception
+    return FLEX_ERR_INVALID;
 }
 
-int flex_order_deg(const flex_csr *A, int descending, uint32_t *rank) {
+int flex_order_deg(const flex_csr *A, int descending, uint32_t *rank) try {
     if (!rank) return FLEX_ERR_INVALID;
     int rc = flex::validate_csr(A);
     if (rc) return rc;
@@ -140,10 +153,16 @@ int flex_order_deg(const flex_csr *A, int descending, uint32_t *rank) {
     });
     for (int32_t i = 0; i < n; ++i) rank[by[i]] = static_cast<uint32_t>(i);
     return FLEX_OK;
+} catch (const std::bad_alloc &) {
+    return FLEX_ERR_NOMEM;
+} catch (const std::length_error &) {
+    return FLEX_ERR_NOMEM;
+} catch (...) {  // nothing crosses the C ABI as an exception
+    return FLEX_ERR_INVALID;
 }
 
 int flex_perm_csr(const flex_csr *A, const uint32_t *rank, int32_t *vo_mp, uint32_t *rowPtr2, uint32_t *col2,
-                  float *vals2) {
+                  float *vals2) try {
     if (!rank || !vo_mp || !rowPtr2 || (A && A->nnz > 0 && (!col2 || !vals2))) return FLEX_ERR_INVALID;
     int rc = flex::validate_csr(A);
     if (rc) return rc;
@@ -169,6 +188,12 @@ int flex_perm_csr(const flex_csr *A, const uint32_t *rank, int32_t *vo_mp, uint3
         }
     }
     return FLEX_OK;
+} catch (const std::bad_alloc &) {
+    return FLEX_ERR_NOMEM;
+} catch (const std::length_error &) {
+    return FLEX_ERR_NOMEM;
+} catch (...) {  // nothing crosses the C ABI as an exception
+    return FLEX_ERR_INVALID;
 }
 
 }  // extern "C"

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <numeric>
 #include <thread>
+#include <stdexcept>
 #include <vector>
 
 #include "internal.h"
@@ -123,7 +124,7 @@ extern "C" int flex_synth_preset(const char *name, int scale, flex_synth_params 
     return FLEX_ERR_INVALID;
 }
 
-extern "C" int flex_synth_graph(const flex_synth_params *p, flex_host_csr *out) {
+extern "C" int flex_synth_graph(const flex_synth_params *p, flex_host_csr *out) try {
     if (!p || !out) return FLEX_ERR_INVALID;
     std::memset(out, 0, sizeof *out);
     const int64_t n = p->n, nnz = p->nnz;
@@ -320,4 +321,10 @@ extern "C" int flex_synth_graph(const flex_synth_params *p, flex_host_csr *out) 
         out->n_nodes_z_deg += (z_out && z_in);
     }
     return FLEX_OK;
+} catch (const std::bad_alloc &) {
+    return FLEX_ERR_NOMEM;
+} catch (const std::length_error &) {
+    return FLEX_ERR_NOMEM;
+} catch (...) {  // nothing crosses the C ABI as an exception
+    return FLEX_ERR_INVALID;
 }

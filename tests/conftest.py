@@ -12,6 +12,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # tools/asan_host.sh points the CPU suite at a sanitizer build of the host code (test infrastructure only)
+    alt = os.environ.get("FLEX_TEST_LIB")
+    if alt:
+        from flex_amd import binding
+        binding._SO = alt
 
 
 @pytest.fixture(scope="session")

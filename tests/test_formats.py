@@ -72,6 +72,22 @@ def test_mtx_errors(tmp_path):
         flex_amd.mtx_load(str(oob))
     with pytest.raises(flex_amd.FlexError, match="could not be read"):
         flex_amd.mtx_load(str(tmp_path / "missing.mtx"))
+    # found by the sanitizer pass (tools/asan_host.sh): numbers must come from the entry's OWN line, the file may
+    # end without a newline, and a header may not promise more entries than the file can hold
+    hdr = "%%MatrixMarket matrix coordinate real general\n"
+    for name, text in (("short_last.mtx", hdr + "3 3 2\n1 1 1.0\n2"),            # last line: row only, no newline
+                       ("short_mid.mtx", hdr + "3 3 2\n1\n2 2 1.0\n"),            # column would be read from the next line
+                       ("no_value.mtx", hdr + "3 3 2\n1 1\n2 2 1.0\n"),           # value would be read from the next line
+                       ("liar.mtx", hdr + "3 3 4000000000\n1 1 1.0\n"),            # 4e9 entries promised
+                       ("huge.mtx", hdr + "3 3 99999999999999999999\n1 1 1.0\n")):
+        f = tmp_path / name
+        f.write_bytes(text.encode())
+        with pytest.raises(flex_amd.FlexError):
+            flex_amd.mtx_load(str(f))
+    ok = tmp_path / "no_newline.mtx"
+    ok.write_bytes((hdr + "2 2 2\n1 1 1.5\n2 2 -2").encode())                    # complete entry, no final newline: fine
+    a = flex_amd.mtx_load(str(ok))
+    assert a.nnz == 2 and np.array_equal(a.vals, np.array([1.5, -2.0], dtype=np.float32))
 
 
 def test_mtx_to_csv_is_what_dataloader_reads(tmp_path):
@@ -137,3 +153,49 @@ def test_permutation_cache_round_trip_and_refusals(tmp_path, golden):
     flex_amd.perm_save(str(tmp_path / "dup.perm"), dup, fp)
     with pytest.raises(flex_amd.FlexError, match="does not parse"):  # not a permutation
         flex_amd.perm_load(str(tmp_path / "dup.perm"), a.n, fp)
+
+
+def test_parsers_survive_mutated_inputs(tmp_path):
+    """600 seeded mutations (byte flips, truncations, duplicated and deleted spans, huge numbers) of a small CSV and
+    a small MatrixMarket file: every load either fails with a FlexError or returns a CSR that passes the
+    library's own validation -- never a crash, a hang or an inconsistent structure (tools/asan_host.sh runs
+    this under AddressSanitizer / UBSan)."""
+    rng = np.random.default_rng(77)
+    csv = open(os.path.join(GOLDEN, "a_mat.csv"), "rb").read()
+    mtx = (b"%%MatrixMarket matrix coordinate real general\n% comment\n6 6 9\n1 1 1.5\n2 1 -2\n3 3 4e-1\n6 2 1\n"
+           b"4 5 2.25\n5 5 1\n1 6 3\n2 2 7\n6 6 -1\n")
+    bombs = [b"99999999999999999999", b"-1", b"1e400", b"nan", b"4294967296", b",,,,", b"\n\n\n", b"\x00", b"2147483648 2147483648 1"]
+
+    def mutate(data):
+        d = bytearray(data)
+        for _ in range(int(rng.integers(1, 4))):
+            op = int(rng.integers(0, 5))
+            pos = int(rng.integers(0, max(1, len(d))))
+            if op == 0 and d:
+                d[pos % len(d)] = int(rng.integers(0, 256))
+            elif op == 1:
+                d = d[:pos]
+            elif op == 2:
+                span = d[pos:pos + int(rng.integers(1, 40))]
+                d[pos:pos] = span
+            elif op == 3:
+                del d[pos:pos + int(rng.integers(1, 40))]
+            else:
+                d[pos:pos] = bombs[int(rng.integers(0, len(bombs)))]
+        return bytes(d)
+
+    ok = bad = 0
+    for i in range(600):
+        is_csv = i % 2 == 0
+        path = tmp_path / ("m.csv" if is_csv else "m.mtx")
+        path.write_bytes(mutate(csv if is_csv else mtx))
+        try:
+            a = flex_amd.csv_load(str(path)) if is_csv else flex_amd.mtx_load(str(path), sort_columns=bool(i % 4 == 1))
+        except flex_amd.FlexError:
+            bad += 1
+            continue
+        ok += 1
+        rp = a.rowPtr.astype(np.int64)
+        assert len(rp) == a.m + 1 and rp[0] == 0 and np.all(np.diff(rp) >= 0) and rp[-1] == a.nnz == len(a.col) == len(a.vals)
+        assert a.nnz == 0 or int(a.col.max()) < a.n
+    assert ok > 20 and bad > 20, (ok, bad)  # the mutations exercise both outcomes
