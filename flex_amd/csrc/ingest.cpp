@@ -401,8 +401,25 @@ int flex_csr_load_bin(const char *path, flex_host_csr *out) try {
         std::fclose(f);
         return FLEX_ERR_FORMAT;
     }
-    std::vector<uint32_t> rp(static_cast<size_t>(hdr[0]) + 1), col(static_cast<size_t>(hdr[2]));
-    std::vector<float> vals(static_cast<size_t>(hdr[2]));
+    // the header must describe exactly this file: nothing is allocated on the word of a corrupt header
+    const long body = std::ftell(f);
+    std::fseek(f, 0, SEEK_END);
+    const long total = std::ftell(f);
+    std::fseek(f, body, SEEK_SET);
+    if (body < 0 || total < 0 || static_cast<int64_t>(total - body) != 4 * (hdr[0] + 1) + 8 * hdr[2]) {
+        std::fclose(f);
+        return FLEX_ERR_FORMAT;
+    }
+    std::vector<uint32_t> rp, col;
+    std::vector<float> vals;
+    try {
+        rp.resize(static_cast<size_t>(hdr[0]) + 1);
+        col.resize(static_cast<size_t>(hdr[2]));
+        vals.resize(static_cast<size_t>(hdr[2]));
+    } catch (...) {
+        std::fclose(f);
+        throw;
+    }
     const bool ok = std::fread(rp.data(), sizeof(uint32_t), rp.size(), f) == rp.size() &&
                     std::fread(col.data(), sizeof(uint32_t), col.size(), f) == col.size() &&
                     std::fread(vals.data(), sizeof(float), vals.size(), f) == vals.size();

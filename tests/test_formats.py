@@ -116,6 +116,12 @@ def test_csv_and_binary_round_trip_pubmed(tmp_path):
         f.write(b"not a csr file at all")
     with pytest.raises(flex_amd.FlexError, match="does not parse"):
         flex_amd.csr_load_bin(str(tmp_path / "junk.bin"))
+    raw = open(tmp_path / "p.bin", "rb").read()
+    for name, data in (("short.bin", raw[:-4]), ("long.bin", raw + b"\0\0\0\0"),
+                       ("liar.bin", raw[:8] + np.array([a.m, a.n, 2 ** 31], dtype=np.int64).tobytes() + raw[32:])):
+        (tmp_path / name).write_bytes(data)  # header and file size must agree before anything is allocated
+        with pytest.raises(flex_amd.FlexError, match="does not parse"):
+            flex_amd.csr_load_bin(str(tmp_path / name))
 
 
 def test_permutation_cache_round_trip_and_refusals(tmp_path, golden):
