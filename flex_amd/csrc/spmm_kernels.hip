@@ -57,26 +57,100 @@ __device__ __forceinline__ void fma4(float4 &acc, float v, const float4 &b) {
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
-// x[l] + x[l ^ 8]: the partner sits in the same 16-lane row, 8 lanes over: DPP row_ror:8 (pure VALU).
-__device__ __forceinline__ float xor8_sum(float x) {
-    const int u = __float_as_int(x);
-    return x + __int_as_float(__builtin_amdgcn_update_dpp(u, u, 0x128 /* row_ror:8 */, 0xF, 0xF, false));
+// Row epilogue.  The S = 64/G slots of a wave each hold a partial float4 of the same C row.  They are
+// combined by a reduce-SCATTER, not an all-reduce: at every level a lane adds its partner's half of the
+// values and hands the other half over, so the value count halves with the lane distance and the row ends
+// up spread over the lanes -- one cross-lane instruction and one add per PAIR of values, no copies:
+//   pair8  (a,b): lanes with bit 3 clear get a[l]+a[l^8],  the others b[l]+b[l^8]   (two masked DPP adds)
+//   pair16 (a,b): even 16-lane rows get a[l]+a[l^16], odd rows b[l]+b[l^16]         (v_permlane16_swap + add)
+//   pair32 (a,b): the lower wave half gets a[l]+a[l^32], the upper half b[l]+b[l^32] (v_permlane32_swap + add)
+__device__ __forceinline__ float pair8(float a, float b) {
+    float r;
+    // row_ror:8 = the lane 8 over in the same 16-lane row; bank_mask picks lanes 0-7 / 8-15 of every row.
+    // s_nop: a DPP read needs two wait states after a VALU write of its source, and the compiler's hazard
+    // recognizer does not look inside inline asm.
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"
+        : "=&v"(r)
+        : "v"(a), "v"(b));
+    return r;
 }
 
-// x[l] + x[l ^ 16]: v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the
-// even rows of its second; fed (x, x) the two results hold {row0,row0,row2,row2} and {row1,row1,row3,row3}.
-__device__ __forceinline__ float xor16_sum(float x) {
-    const uint32_t u = __float_as_uint(x);
-    const auto sw = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+__device__ __forceinline__ float pair16(float a, float b) {
+    // v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second:
+    // (a,b) -> {a0,b0,a2,b2}, {a1,b1,a3,b3}; their sum is a0+a1 on row 0, b0+b1 on row 1, ...
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
 }
 
-// x[l] + x[l ^ 32] in every lane.  v_permlane32_swap exchanges the upper half of its first
-// operand with the lower half of its second; fed (x, x) it yields {lo,lo} and {hi,hi}.
-__device__ __forceinline__ float xor32_sum(float x) {
-    const uint32_t u = __float_as_uint(x);
-    const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+__device__ __forceinline__ float pair32(float a, float b) {
+    // v_permlane32_swap exchanges the upper half of its first operand with the lower half of its second:
+    // (a,b) -> {a.lo,b.lo}, {a.hi,b.hi}; their sum is a.lo+a.hi on the lower half, b.lo+b.hi on the upper
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
+
+// What a lane holds of a finished row, and which column(s) of its tile.  Measured on MI355X (tools/ab.py):
+// the scattered form saves ~30 VALU instructions per row at G=8, where short rows make the epilogue the
+// largest VALU term (flickr k=32: 17.3 -> 14.8 us); at G=16/32 it only trades 16-byte stores from the 16/32
+// lanes of one slot for 4/8-byte stores strided across the wave (flickr k=64 +3.5 %, k=128 +-0), so those
+// widths keep the all-reduce and the contiguous float4 store:
+//   G=64: 4 values at c0, every lane          (no reduction)
+//   G=32: 4 values at c0, lanes of slot 0     (all-reduce over 2 slots)
+//   G=16: 4 values at c0, lanes of slot 0     (all-reduce over 4 slots)
+//   G=8 : 1 value  at c0 + 2*bit3 + bit4, lower wave half  (pair8 twice, pair16, then both halves summed)
+template <int G>
+struct RowOut {
+    static constexpr int kVals = G == 8 ? 1 : 4;
+    float v[kVals];
+};
+
+template <int G>
+__device__ __forceinline__ int row_out_col(int lane, int c0) {
+    if constexpr (G == 8) return c0 + 2 * ((lane >> 3) & 1) + ((lane >> 4) & 1);
+    else return c0;
+}
+
+template <int G>
+__device__ __forceinline__ bool row_out_lane(int lane) {  // does this lane store
+    return G == 8 ? lane < 32 : lane < G;
+}
+
+template <int G>
+__device__ __forceinline__ RowOut<G> reduce_row(const float4 &acc) {
+    RowOut<G> o;
+    if constexpr (G == 8) {
+        const float t = pair16(pair8(acc.x, acc.z), pair8(acc.y, acc.w));
+        o.v[0] = pair32(t, t);  // both halves hold the same columns: plain sum, the lower half stores
+    } else {
+        float4 r = acc;
+        if constexpr (G <= 16) {
+            r.x = pair16(r.x, r.x);
+            r.y = pair16(r.y, r.y);
+            r.z = pair16(r.z, r.z);
+            r.w = pair16(r.w, r.w);
+        }
+        if constexpr (G <= 32) {
+            r.x = pair32(r.x, r.x);
+            r.y = pair32(r.y, r.y);
+            r.z = pair32(r.z, r.z);
+            r.w = pair32(r.w, r.w);
+        }
+        o.v[0] = r.x; o.v[1] = r.y; o.v[2] = r.z; o.v[3] = r.w;
+    }
+    return o;
+}
+
+// non-temporal store of a lane's share of a C row (ptr already points at its first column)
+template <int G>
+__device__ __forceinline__ void store_row_out(float *ptr, const RowOut<G> &o) {
+    if constexpr (RowOut<G>::kVals == 4) {
+        const v4f val = {o.v[0], o.v[1], o.v[2], o.v[3]};
+        __builtin_nontemporal_store(val, reinterpret_cast<v4f *>(ptr));
+    } else {
+        __builtin_nontemporal_store(o.v[0], ptr);
+    }
 }
 
 constexpr int kWindowRecs = 256;  // records staged per wave and window (2 KiB of LDS)
@@ -146,56 +220,32 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
     uint32_t ti = 0;                                          // current task
     uint32_t row_end = __builtin_amdgcn_readlane(my_beg, 1);  // where it ends in the record stream
     float4 acc = {0.f, 0.f, 0.f, 0.f};
-    float4 piece_sum = {0.f, 0.f, 0.f, 0.f};
-    uint32_t piece_dst = 0;  // kPartialFlag | slot once this chunk turned out to be a piece of a split row
+    const int out_col = row_out_col<G>(lane, c0);              // first column this lane stores of a finished row
+    const bool out_ok = col_ok && row_out_lane<G>(lane);
+    // A piece of a split row is a chunk of its own (planner invariant): its single task is never flushed in
+    // the loops; the sum is reduced and combined after them, where the gather registers are dead.
+    const uint32_t dst0 = __builtin_amdgcn_readlane(my_dst, 0);
+    const bool piece = nt == 1 && (dst0 & kPartialFlag) != 0;
 
     // Write out the task that ends at the current stream position (and any empty rows behind it).
     // row_end is kept at ~0 once the chunk's tasks are exhausted, so the per-step test in the hot
     // loop is ONE scalar compare.
     auto flush = [&](uint32_t pos) {
         do {
-            float4 r = acc;
-            // combine the S = 64/G slots of the row without touching the LDS: DPP within a 16-lane row,
-            // v_permlane16_swap across rows, v_permlane32_swap across the wave halves
-            if constexpr (G <= 8) {
-                r.x = xor8_sum(r.x);
-                r.y = xor8_sum(r.y);
-                r.z = xor8_sum(r.z);
-                r.w = xor8_sum(r.w);
-            }
-            if constexpr (G <= 16) {
-                r.x = xor16_sum(r.x);
-                r.y = xor16_sum(r.y);
-                r.z = xor16_sum(r.z);
-                r.w = xor16_sum(r.w);
-            }
-            if constexpr (G <= 32) {
-                r.x = xor32_sum(r.x);
-                r.y = xor32_sum(r.y);
-                r.z = xor32_sum(r.z);
-                r.w = xor32_sum(r.w);
-            }
+            const RowOut<G> o = reduce_row<G>(acc);
             const uint32_t dst = __builtin_amdgcn_readlane(my_dst, ti);
-            if (!(dst & kPartialFlag)) {
 #ifdef FLEX_ABL_NOSTORE  // timing-only ablation: the store is kept in the code but never executes
-                if (slot == 0 && col_ok && p.k < 0) {
+            if (out_ok && p.k < 0)
 #else
-                if (slot == 0 && col_ok) {
+            if (out_ok)
 #endif
-                    const v4f val = {r.x, r.y, r.z, r.w};
-                    __builtin_nontemporal_store(val, reinterpret_cast<v4f *>(C + static_cast<uint64_t>(dst) * ldc + c0));
-                }
-            } else {
-                // a piece of a split row is a chunk of its own (planner invariant): remember its sum and
-                // combine after the loops, where the gather registers are dead (keeps the hot loop lean)
-                piece_sum = r;
-                piece_dst = dst;
-            }
+                store_row_out<G>(C + static_cast<uint64_t>(dst) * ldc + out_col, o);
             acc = {0.f, 0.f, 0.f, 0.f};
             ++ti;
             row_end = ti < nt ? __builtin_amdgcn_readlane(my_beg, ti + 1) : 0xFFFFFFFFu;
         } while (row_end == pos);
     };
+    if (piece) row_end = 0xFFFFFFFFu;
     if (nt == 0) row_end = 0xFFFFFFFFu;
     if (row_end == zb) flush(zb);  // leading empty rows
 
@@ -266,11 +316,15 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
 #ifdef FLEX_ABL_NOFLUSH
     if (nt > 0) { ti = nt - 1; flush(0xFFFFFFFEu); }  // pos != the ~0 sentinel, or the do-while never ends
 #endif
-    if (piece_dst & kPartialFlag) {
-        const float4 r = piece_sum;
-        const uint32_t ps = piece_dst & ~kPartialFlag;
+    if (piece) {
+        const RowOut<G> o = reduce_row<G>(acc);
+        const uint32_t ps = dst0 & ~kPartialFlag;
         if (!p.fused_fixup) {  // partial sums are combined by spmm_fixup_kernel after this launch
-            if (slot == 0 && col_ok) *reinterpret_cast<float4 *>(p.partial + static_cast<uint64_t>(ps) * k + c0) = r;
+            if (out_ok) {
+                float *pp = p.partial + static_cast<uint64_t>(ps) * k + out_col;
+#pragma unroll
+                for (int i = 0; i < RowOut<G>::kVals; ++i) pp[i] = o.v[i];
+            }
         } else {
             // Combined inside this launch by whichever piece finishes LAST (cdna guide G16, counter form
             // with write-through payload): (1) the partial sum is stored write-through (sc1), so it is at
@@ -280,9 +334,14 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
             // adds them in PIECE order -- the sum is reproducible although the reducer is not -- and
             // re-arms the counter for the next launch.
             const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, p.partial_bytes, 0x00020000);
-            if (slot == 0 && col_ok) {
-                const v4u pv = {__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z), __float_as_uint(r.w)};
-                __builtin_amdgcn_raw_buffer_store_b128(pv, prsrc, (ps * k + c0) * 4u, 0, 16 /* sc1 */);
+            if (out_ok) {
+                const uint32_t off = (ps * k + out_col) * 4u;
+                if constexpr (RowOut<G>::kVals == 4) {
+                    const v4u pv = {__float_as_uint(o.v[0]), __float_as_uint(o.v[1]), __float_as_uint(o.v[2]), __float_as_uint(o.v[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(pv, prsrc, off, 0, 16 /* sc1 */);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o.v[0]), prsrc, off, 0, 16 /* sc1 */);
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const uint32_t sidx = p.piece_row[ps];
