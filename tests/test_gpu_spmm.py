@@ -555,3 +555,19 @@ def test_seeded_fuzz_over_shapes_degrees_widths_schedules():
         st, info = p.stats(), p.info()
         assert st["records"] >= a.nnz and info["n_slots"] >= info["n_chunks"] and info["nnz"] == a.nnz, tag
         p.destroy()
+
+
+@pytest.mark.parametrize("k", [32, 64, 128])
+def test_two_launch_form_of_split_rows(monkeypatch, k):
+    """FLEX_FUSED_FIXUP=2: the vector kernel leaves the partial sums of split rows to spmm_fixup_kernel (the form
+    the generic kernel always uses, and the fallback when the workspace exceeds the 4 GiB buffer range)."""
+    a = random_csr(2500, 2500, 10, seed=51, long_rows={1: 2400, 8: 1100, 900: 300})
+    B = random_B(2500, k, 6)
+    monkeypatch.setenv("FLEX_FUSED_FIXUP", "2")
+    p = Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER)
+    assert p.info()["n_split_rows"] >= 3
+    C1 = run_plan(p, B)
+    assert_matches_oracle(a, B, C1)
+    monkeypatch.delenv("FLEX_FUSED_FIXUP")
+    C2 = run_plan(Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER), B)
+    assert np.array_equal(C1, C2)  # both forms add the pieces in piece order: bit-identical
