@@ -4,12 +4,18 @@
 #include <hip/hip_runtime.h>
 #include <rocblas/rocblas.h>
 
+#include <cstdlib>
 #include <new>
 
 #include "../../include/flex_axw.h"
 
+extern "C" hipError_t flex_axw_gemm_launch(const float *L, const float *Wp, float *Out, int n, int dim, int cp, int n_cus,
+                                           hipStream_t s);  // axw_kernels.hip
+
 struct flex_axw {
     int32_t n = 0;
+    int n_cus = 0;
+    bool use_blas = false;  // FLEX_AXW_BLAS=1, or a shape the MFMA kernel does not take (dim % 4 != 0, dim > 128, n < 32)
     int dim = 0, c = 0, cp = 0, device = 0;
     flex_plan *plan_c = nullptr, *plan_dim = nullptr;
     float *d_xw = nullptr;  // n x cp
@@ -26,7 +32,8 @@ namespace {
 int hip_fail(hipError_t e) { return e == hipSuccess ? FLEX_OK : (e == hipErrorOutOfMemory ? FLEX_ERR_NOMEM : FLEX_ERR_HIP); }
 
 // C_rm[n x cp] = L_rm[n x dim] * Wp_rm[dim x cp]   <=>   column-major  C^T = Wp^T * L^T
-int gemm_rm(flex_axw *h, const float *L, float *Cout) {
+int gemm_rm(flex_axw *h, const float *L, float *Cout, hipStream_t s) {
+    if (!h->use_blas) return hip_fail(flex_axw_gemm_launch(L, h->d_wp, Cout, h->n, h->dim, h->cp, h->n_cus, s));
     const float one = 1.0f, zero = 0.0f;
     const rocblas_status st = rocblas_sgemm(h->blas, rocblas_operation_none, rocblas_operation_none, h->cp, h->n, h->dim, &one,
                                             h->d_wp, h->cp, L, h->dim, &zero, Cout, h->cp);
@@ -87,6 +94,13 @@ int flex_axw_create(flex_axw **out, const flex_csr *A, int dim, int c, int devic
     if (!rc) rc = hip_fail(hipMemset(h->d_wp, 0, static_cast<size_t>(dim) * h->cp * sizeof(float)));
     for (int i = 0; i < 3 && !rc; ++i) rc = hip_fail(hipEventCreate(&h->ev[i]));
     if (!rc && rocblas_create_handle(&h->blas) != rocblas_status_success) rc = FLEX_ERR_UNSUPPORTED;
+    if (!rc) {
+        hipDeviceProp_t prop;
+        rc = hip_fail(hipGetDeviceProperties(&prop, device));
+        h->n_cus = prop.multiProcessorCount;
+        const char *e = std::getenv("FLEX_AXW_BLAS");
+        h->use_blas = (e && *e == '1') || dim % 4 != 0 || dim > 128 || h->n < 32;
+    }
     if (prev >= 0) (void)hipSetDevice(prev);
     if (rc) {
         flex_axw_destroy(h);
@@ -114,14 +128,14 @@ int flex_axw_run(flex_axw *h, int order, const float *dX, const float *dW, float
                                        static_cast<size_t>(h->c) * sizeof(float), static_cast<size_t>(h->dim), hipMemcpyDeviceToDevice, s));
     if (!rc) rc = mark(0);
     if (order == FLEX_AXW_A_XW) {  // run1: cusp.cu:18-75
-        if (!rc) rc = gemm_rm(h, dX, h->d_xw);
+        if (!rc) rc = gemm_rm(h, dX, h->d_xw, s);
         if (!rc) rc = mark(1);
         if (!rc) rc = flex_spmm(h->plan_c, h->d_xw, dOut, stream);
         if (!rc) rc = mark(2);
     } else {  // run2: cusp.cu:121-178
         if (!rc) rc = flex_spmm(h->plan_dim, dX, h->d_ax, stream);
         if (!rc) rc = mark(1);
-        if (!rc) rc = gemm_rm(h, h->d_ax, dOut);
+        if (!rc) rc = gemm_rm(h, h->d_ax, dOut, s);
         if (!rc) rc = mark(2);
     }
     if (!rc && timed) {
