@@ -5,7 +5,8 @@
  * ≙ run1 / run2 of cusp.cu (3-104, 106-208), the AXW block of main.cu:22-77 (compiled out in the
  * reference: `//#define AXW 1`):  run1 = A*(X*W): SGEMM then SpMM at k = c;  run2 = (A*X)*W: SpMM at
  * k = dim then SGEMM.  Here the SpMM is the engine's (flex_spmm, a plan per width) instead of
- * cusparseSpMM, the SGEMM is rocBLAS, and all dense operands are ROW-major (the reference's are
+ * cusparseSpMM, the dense product is a hand-written fp32 MFMA kernel for dim <= 128 (axw_kernels.hip;
+ * rocBLAS SGEMM for other widths), and all dense operands are ROW-major (the reference's are
  * column-major, cusp.cu:31-32, 55-60) so that they chain with flex_spmm without a transpose.
  * Kept in its own library: the engine (libflex_spmm.so) never depends on rocBLAS.
  */
