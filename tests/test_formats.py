@@ -90,6 +90,23 @@ def test_mtx_errors(tmp_path):
     assert a.nnz == 2 and np.array_equal(a.vals, np.array([1.5, -2.0], dtype=np.float32))
 
 
+def test_conv_binary_is_the_references_mtx2csr(tmp_path):
+    """flex_amd/lib/conv in.mtx out.csv (≙ prepare_mtx_data.sh's `conv`): the CSV it writes loads back to the CSR the
+    library reads from the MatrixMarket file directly; bad input exits non-zero."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(flex_amd.lib_path()), "conv")
+    assert os.path.exists(exe)
+    src = tmp_path / "g.mtx"
+    src.write_text("%%MatrixMarket matrix coordinate real symmetric\n4 4 5\n1 1 2.0\n2 1 -1.5\n3 3 1.0\n4 2 0.25\n4 4 3.0\n")
+    out = subprocess.run([exe, str(src), str(tmp_path / "g.csv"), "--sort"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "m = 4,   n = 4" in out.stdout, out.stdout + out.stderr
+    a, b = flex_amd.csv_load(str(tmp_path / "g.csv")), flex_amd.mtx_load(str(src), sort_columns=True)
+    assert np.array_equal(a.rowPtr, b.rowPtr) and np.array_equal(a.col, b.col) and np.array_equal(a.vals, b.vals)
+    assert a.nnz == 7  # the two off-diagonal entries are mirrored
+    bad = subprocess.run([exe, str(tmp_path / "missing.mtx"), str(tmp_path / "x.csv")], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "could not be read" in bad.stderr
+
+
 def test_mtx_to_csv_is_what_dataloader_reads(tmp_path):
     """prepare_mtx_data.sh: mtx -> conv -> csv -> DataLoader.  Same pipeline, exact fp32 round trip."""
     path = tmp_path / "g.mtx"
