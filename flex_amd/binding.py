@@ -70,7 +70,7 @@ class _SynthParams(C.Structure):  # flex_synth_params
 # every symbol include/flex_spmm.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = [
     "flex_plan_create", "flex_plan_create_ld", "flex_plan_create_mapped", "flex_plan_create_rows", "flex_spmm",
-    "flex_plan_destroy", "flex_plan_get_info", "flex_plan_get_stats", "flex_hbm_probe", "flex_gather_rows", "flex_csv_load", "flex_mtx_load",
+    "flex_plan_destroy", "flex_plan_get_info", "flex_plan_get_stats", "flex_plan_self_check", "flex_hbm_probe", "flex_gather_rows", "flex_csv_load", "flex_mtx_load",
     "flex_csv_save", "flex_csr_save_bin", "flex_csr_load_bin", "flex_csr_fingerprint", "flex_perm_save", "flex_perm_load",
     "flex_host_csr_free", "flex_fill_dense_rand", "flex_order_rcm", "flex_order_cluster", "flex_order_gorder", "flex_perm_csr",
     "flex_order_deg", "flex_order_dfs", "flex_shard_rows", "flex_synth_graph", "flex_synth_preset", "flex_strerror", "flex_last_hip_error",
@@ -116,6 +116,7 @@ def lib():
         L.flex_plan_destroy.argtypes = [vp]
         L.flex_plan_get_info.argtypes = [vp, C.POINTER(_PlanInfo)]
         L.flex_plan_get_stats.argtypes = [vp, C.POINTER(_PlanStats)]
+        L.flex_plan_self_check.argtypes = [vp]
         L.flex_gather_rows.argtypes = [vp, vp, vp, i64, i32, vp]
         L.flex_hbm_probe.argtypes = [i32, i64, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.flex_csv_load.argtypes = [C.c_char_p, C.POINTER(_HostCsr)]
@@ -358,6 +359,10 @@ class Plan:
         st = _PlanStats()
         _check(lib().flex_plan_get_stats(self._h, C.byref(st)), "flex_plan_get_stats")
         return {f: getattr(st, f) for f, _ in _PlanStats._fields_}
+
+    def self_check(self):
+        """flex_plan_self_check: the device image of the plan is a partition of the work (raises FlexError if not)."""
+        _check(lib().flex_plan_self_check(self._h), "flex_plan_self_check")
 
     def spmm(self, dB_ptr: int, dC_ptr: int, stream: int = 0):
         _check(lib().flex_spmm(self._h, dB_ptr, dC_ptr, stream), "flex_spmm")

@@ -68,6 +68,8 @@ struct flex_plan {
     uint32_t partial_bytes = 0;
     bool fused_fixup = false;
     uint32_t n_tasks = 0, n_chunks = 0, n_slots = 0, n_split = 0, n_partials = 0;  // n_slots: chunk table incl. padding
+    uint64_t n_records = 0;   // nnz + padding
+    int64_t c_rows = 0;       // rows of C the plan writes into (m, or hostA->m for a mapped plan)
     int64_t device_bytes = 0;
     double plan_ms = 0;
     bool has_stats = false;
@@ -280,6 +282,8 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     if (rec.size() >= (size_t(1) << 32)) return FLEX_ERR_UNSUPPORTED;  // 32-bit record offsets
 
     p->n_tasks = static_cast<uint32_t>(t_dst.size());
+    p->n_records = rec.size();
+    p->c_rows = dst_map ? A->m : m;
     p->n_chunks = static_cast<uint32_t>(w_task.size() - 1);
     p->n_split = static_cast<uint32_t>(split.size());
     p->n_partials = n_partials;
@@ -489,6 +493,89 @@ int flex_plan_get_stats(const flex_plan *p, flex_plan_stats *o) {
     if (!p->has_stats) return FLEX_ERR_UNSUPPORTED;
     *o = p->stats;
     return FLEX_OK;
+}
+
+// ≙ the reference's tiler round-trip (mat.cu:905-940: every entry of the pillar format exists exactly once,
+// the queues are contiguous): read the plan's DEVICE image back and check that it is a partition --
+// chunks tile the tasks, tasks tile the records, every record names a valid B row, every C row is written by
+// exactly one task or by exactly one split row whose pieces are contiguous partial slots, padding entries of
+// the chunk table are empty.  Independent of the planner's host arrays: it validates what the kernels read.
+int flex_plan_self_check(const flex_plan *p) try {
+    if (!p) return FLEX_ERR_INVALID;
+    if (p->m == 0) return FLEX_OK;
+    int cur = -1;
+    FLEX_HIP_TRY(hipGetDevice(&cur));
+    if (cur != p->device) FLEX_HIP_TRY(hipSetDevice(p->device));
+    std::vector<uint2> rec(p->n_records);
+    std::vector<uint32_t> t_beg(static_cast<size_t>(p->n_tasks) + 1), t_dst(p->n_tasks), piece_row(p->n_partials);
+    std::vector<uint4> chunk(p->n_slots);
+    std::vector<SplitRow> split(p->n_split);
+    auto down = [&](void *dst, const void *src, size_t bytes) { return bytes == 0 || hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess; };
+    const bool ok_copy = down(rec.data(), p->d_rec, rec.size() * sizeof(uint2)) && down(t_beg.data(), p->d_t_beg, t_beg.size() * 4) &&
+                         down(t_dst.data(), p->d_t_dst, t_dst.size() * 4) && down(chunk.data(), p->d_chunk, chunk.size() * sizeof(uint4)) &&
+                         down(split.data(), p->d_split, split.size() * sizeof(SplitRow)) && down(piece_row.data(), p->d_piece_row, piece_row.size() * 4);
+    if (cur != p->device) (void)hipSetDevice(cur);
+    if (!ok_copy) return FLEX_ERR_HIP;
+
+    // tasks tile the record stream
+    if (t_beg[0] != 0 || t_beg[p->n_tasks] != p->n_records) return FLEX_ERR_FORMAT;
+    for (uint32_t t = 0; t < p->n_tasks; ++t)
+        if (t_beg[t] > t_beg[t + 1]) return FLEX_ERR_FORMAT;
+    // chunks tile the tasks (in table order, skipping the empty padding entries), each within the kernel's limits
+    uint32_t next_task = 0, real = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> seen;  // real chunks as (first task, #tasks)
+    for (const uint4 &c : chunk) {
+        if (c.y == 0) {
+            if (c.x | c.z | c.w) return FLEX_ERR_FORMAT;
+            continue;
+        }
+        if (c.y > 63 || c.x + c.y > p->n_tasks || c.z != t_beg[c.x] || c.w != t_beg[c.x + c.y]) return FLEX_ERR_FORMAT;
+        seen.emplace_back(c.x, c.y);
+        ++real;
+    }
+    if (real != p->n_chunks) return FLEX_ERR_FORMAT;
+    std::sort(seen.begin(), seen.end());
+    for (const auto &c : seen) {
+        if (c.first != next_task) return FLEX_ERR_FORMAT;
+        next_task += c.second;
+    }
+    if (next_task != p->n_tasks) return FLEX_ERR_FORMAT;
+    // records name valid B rows
+    const uint64_t row_bytes = static_cast<uint64_t>(p->ldb) * 4u;
+    for (const uint2 &r : rec) {
+        const uint64_t col = p->off32 ? r.x / row_bytes : r.x;
+        if (col >= static_cast<uint64_t>(p->n) || (p->off32 && r.x % row_bytes != 0)) return FLEX_ERR_FORMAT;
+    }
+    // every C row exactly once; pieces of a split row are consecutive tasks on consecutive partial slots
+    std::vector<uint8_t> written(static_cast<size_t>(p->c_rows), 0);
+    uint32_t next_partial = 0;
+    for (uint32_t t = 0; t < p->n_tasks; ++t) {
+        const uint32_t d = t_dst[t];
+        if (d & kPartialFlag) {
+            if ((d & ~kPartialFlag) != next_partial++) return FLEX_ERR_FORMAT;
+        } else {
+            if (d >= p->c_rows || written[d]++) return FLEX_ERR_FORMAT;
+        }
+    }
+    if (next_partial != p->n_partials) return FLEX_ERR_FORMAT;
+    uint32_t first = 0;
+    for (uint32_t i = 0; i < p->n_split; ++i) {
+        const SplitRow &sr = split[i];
+        if (sr.first != first || sr.count < 1 || sr.row >= p->c_rows || written[sr.row]++) return FLEX_ERR_FORMAT;
+        for (uint32_t j = 0; j < sr.count; ++j)
+            if (piece_row[sr.first + j] != i) return FLEX_ERR_FORMAT;
+        first += sr.count;
+    }
+    if (first != p->n_partials) return FLEX_ERR_FORMAT;
+    // a full plan (not a row shard of a mapped matrix) writes every row of C
+    if (p->c_rows == p->m)
+        for (uint8_t w : written)
+            if (w != 1) return FLEX_ERR_FORMAT;
+    return FLEX_OK;
+} catch (const std::bad_alloc &) {
+    return FLEX_ERR_NOMEM;
+} catch (...) {
+    return FLEX_ERR_INVALID;
 }
 
 int flex_gather_rows(float *dst, const float *src, const int32_t *idx, int64_t n, int k, flex_stream_t stream) {

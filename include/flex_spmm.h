@@ -142,6 +142,13 @@ typedef struct flex_plan_stats {
 } flex_plan_stats;
 int flex_plan_get_stats(const flex_plan *plan, flex_plan_stats *out);
 
+/* ≙ the tiler round-trip self-check of csr2_DiagTiling (mat.cu:905-940): reads the plan's device image back
+ * and verifies that it is a partition of the work -- chunks tile the tasks, tasks tile the records, every
+ * record names a valid B row, every C row is written exactly once (directly or by one split row with
+ * contiguous pieces), table padding is empty.  FLEX_ERR_FORMAT if any invariant fails.  Debug / test aid:
+ * synchronous, O(plan size) host memory. */
+int flex_plan_self_check(const flex_plan *plan);
+
 /* What this box's HBM delivers, for the roofline's denominator (verify BW_peak with a
  * device-to-device copy and report both): GB/s of a read-only streaming pass and of a copy (bytes
  * read + bytes written) over `bytes`-sized buffers (use >= 1 GiB: the Infinity Cache is 256 MiB),

@@ -396,6 +396,22 @@ def test_cxx_multi_gpu_driver_on_one_device():
     assert len(mg) == 1 and mg[0]["errs"] == 0 and mg[0]["gpus"] == 1
 
 
+def test_plan_self_check_on_every_kind_of_plan():
+    """flex_plan_self_check (≙ csr2_DiagTiling's round-trip self-test, mat.cu:905-940) on full, mapped and row-shard
+    plans of a graph with split rows, for one- and multi-tile widths."""
+    a = random_csr(3000, 3000, 20, seed=61, long_rows={4: 2800, 77: 500})
+    rank = flex_amd.order_rcm(a)
+    vo, ap = flex_amd.perm_csr(a, rank)
+    for k in (32, 128, 256):
+        for plan in (Plan(a, k), Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER), Plan(a, k, order=flex_amd.FLEX_ORDER_GORDER),
+                     Plan(ap, k, vo_mp=vo), Plan(ap, k, rows=(0, 1200), col_map=vo), Plan(ap, k, rows=(1200, 3000), col_map=vo),
+                     Plan(a, k, ldb=k + 32, ldc=k + 4)):
+            plan.self_check()
+            plan.destroy()
+    empty = flex_amd.HostCsr(np.zeros(6, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.float32), n=5)
+    Plan(empty, 32).self_check()  # five empty rows: five tasks, no records
+
+
 def test_plan_stats_reuse_and_imbalance_report():
     """≙ alpha_stats_collect / B-Re1 / B-Re2 (mat.cu:944-1065, flex.cu:5217-5223): invariants of the report."""
     from flex_amd import FLEX_PLAN_STATS, FlexError
@@ -555,6 +571,7 @@ def test_seeded_fuzz_over_shapes_degrees_widths_schedules():
         assert cnt == 0, f"{tag}: {cnt} mismatches, max err {max_err:g} on a row of {me_nnz} nnz"
         st, info = p.stats(), p.info()
         assert st["records"] >= a.nnz and info["n_slots"] >= info["n_chunks"] and info["nnz"] == a.nnz, tag
+        p.self_check()  # the device image of the plan is a partition of the work (≙ the tiler round-trip, mat.cu:905-940)
         p.destroy()
 
 
