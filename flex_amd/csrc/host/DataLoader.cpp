@@ -55,6 +55,7 @@ DataLoader::DataLoader(const std::string &data_path, const int di) : dl_original
     rowPtr.assign(h.rowPtr, h.rowPtr + h.m + 1);
     col.assign(h.col, h.col + h.nnz);
     vals.assign(h.vals, h.vals + h.nnz);
+    if (run_options().debug_values) std::fill(vals.begin(), vals.end(), 1.0f);  // opt_debug, DataLoader.cu:51
     m = n = static_cast<size_t>(h.m);
     nnz = static_cast<size_t>(h.nnz);
     c = static_cast<size_t>(h.c);
@@ -89,7 +90,11 @@ void DataLoader::cuda_alloc_cpy() {
     gpuX_bytes = static_cast<int64_t>(n * dim * sizeof(float));
     if (vertex_order_abbr == "OVO") {  // B is drawn once, for the original order only (DataLoader.cu:198-217)
         cpuX.resize(n * dim);
-        FLEX_CHECK(flex_fill_dense_rand(cpuX.data(), static_cast<int64_t>(n), static_cast<int>(dim)));
+        if (run_options().debug_values) {  // opt_debug, DataLoader.cu:202-203
+            for (size_t i = 0; i < n; ++i) std::fill(cpuX.begin() + i * dim, cpuX.begin() + (i + 1) * dim, static_cast<float>(i));
+        } else {
+            FLEX_CHECK(flex_fill_dense_rand(cpuX.data(), static_cast<int64_t>(n), static_cast<int>(dim)));
+        }
         HIP_CHECK(hipMalloc(&gpuX, std::max<int64_t>(gpuX_bytes, 4)));
         HIP_CHECK(hipMemcpy(gpuX, cpuX.data(), gpuX_bytes, hipMemcpyHostToDevice));
     }

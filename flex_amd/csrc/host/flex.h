@@ -11,6 +11,7 @@ struct RunOptions {
     std::string csv;             // append one line per configuration (≙ flex-tile-nperf.csv, flex.cu:4945-4947)
     std::string stats_log;       // write every plan's summary there (≙ flex-tile-stats2.log, flex.cu:4943-4944)
     std::string perm_cache;      // directory of cached orderings (<graph>.<ORD>.perm); empty = recompute every run
+    bool debug_values = false;   // ≙ opt_debug (DataLoader.cu:7, 51, 202-203): every A value 1, X[i][*] = i -- results readable by eye
     bool axw = false;            // run the GCN layer product A*X*W both ways instead of the SpMM loop (main.cu:22-77)
     int gpus = 0;                // > 0: also run the row-sharded multi-GPU path on that many devices (flex_mg.h)
 };

@@ -255,6 +255,9 @@ def test_cxx_host_mirror_cli_pubmed_and_amat(tmp_path):
     assert axw.stdout.count("The results are correct..") == 10 and "A(XW):" in axw.stdout and "(AX)W:" in axw.stdout
     j = [json.loads(ln) for ln in axw.stdout.splitlines() if ln.startswith("{")][-1]
     assert j["c"] == 3 and j["dim"] == 32 and j["a_xw_ms"] > 0 and j["ax_w_ms"] > 0
+    # opt_debug of the reference (A = 1, X[i][*] = i): still zero mismatches against the hipSPARSE gold
+    dbg = subprocess.run([exe, os.path.join(GOLDEN, "a_mat.csv"), "8", "--json", "--debug-values"], capture_output=True, text=True, timeout=300)
+    assert dbg.returncode == 0 and all(json.loads(ln)["errs"] == 0 for ln in dbg.stdout.splitlines() if ln.startswith("{"))
     # second run of the same graph: every ordering comes from the permutation cache and still checks out
     again = subprocess.run([exe, path, k, "--json", "--perm-cache", str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert again.returncode == 0 and "order: cached" not in out.stdout
