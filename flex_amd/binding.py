@@ -60,6 +60,11 @@ class _PlanStats(C.Structure):  # flex_plan_stats
                 ("split_nnz_pct", C.c_double), ("pad_pct", C.c_double), ("n_workgroups", C.c_int64)]
 
 
+class _KernelInfo(C.Structure):  # flex_kernel_info
+    _fields_ = [("vgprs", C.c_int32), ("sgprs", C.c_int32), ("lds_bytes", C.c_int32), ("scratch_bytes", C.c_int32),
+                ("threads_per_block", C.c_int32), ("waves_per_cu", C.c_int32)]
+
+
 class _SynthParams(C.Structure):  # flex_synth_params
     _fields_ = [("n", C.c_int64), ("nnz", C.c_int64), ("alpha", C.c_double),
                 ("community", C.c_int64), ("p_in", C.c_double), ("p_near", C.c_double),
@@ -70,7 +75,7 @@ class _SynthParams(C.Structure):  # flex_synth_params
 # every symbol include/flex_spmm.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = [
     "flex_plan_create", "flex_plan_create_ld", "flex_plan_create_mapped", "flex_plan_create_rows", "flex_spmm",
-    "flex_plan_destroy", "flex_plan_get_info", "flex_plan_get_stats", "flex_plan_self_check", "flex_hbm_probe", "flex_gather_rows", "flex_csv_load", "flex_mtx_load",
+    "flex_plan_destroy", "flex_plan_get_info", "flex_plan_get_stats", "flex_plan_self_check", "flex_plan_kernel_info", "flex_hbm_probe", "flex_gather_rows", "flex_csv_load", "flex_mtx_load",
     "flex_csv_save", "flex_csr_save_bin", "flex_csr_load_bin", "flex_csr_fingerprint", "flex_perm_save", "flex_perm_load",
     "flex_host_csr_free", "flex_fill_dense_rand", "flex_order_rcm", "flex_order_cluster", "flex_order_gorder", "flex_perm_csr",
     "flex_order_deg", "flex_order_dfs", "flex_shard_rows", "flex_synth_graph", "flex_synth_preset", "flex_strerror", "flex_last_hip_error",
@@ -117,6 +122,7 @@ def lib():
         L.flex_plan_get_info.argtypes = [vp, C.POINTER(_PlanInfo)]
         L.flex_plan_get_stats.argtypes = [vp, C.POINTER(_PlanStats)]
         L.flex_plan_self_check.argtypes = [vp]
+        L.flex_plan_kernel_info.argtypes = [vp, C.POINTER(_KernelInfo)]
         L.flex_gather_rows.argtypes = [vp, vp, vp, i64, i32, vp]
         L.flex_hbm_probe.argtypes = [i32, i64, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.flex_csv_load.argtypes = [C.c_char_p, C.POINTER(_HostCsr)]
@@ -359,6 +365,11 @@ class Plan:
         st = _PlanStats()
         _check(lib().flex_plan_get_stats(self._h, C.byref(st)), "flex_plan_get_stats")
         return {f: getattr(st, f) for f, _ in _PlanStats._fields_}
+
+    def kernel_info(self) -> dict:
+        ki = _KernelInfo()
+        _check(lib().flex_plan_kernel_info(self._h, C.byref(ki)), "flex_plan_kernel_info")
+        return {f: getattr(ki, f) for f, _ in _KernelInfo._fields_}
 
     def self_check(self):
         """flex_plan_self_check: the device image of the plan is a partition of the work (raises FlexError if not)."""

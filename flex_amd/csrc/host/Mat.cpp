@@ -50,6 +50,10 @@ void Mat::alpha_stats_collect(FILE *stream) const {
                  static_cast<long long>(s.chunk_rec_max), s.chunk_rec_mean, s.xcd_imb_pct);
     std::fprintf(stream, " Work %.1f%% in %lld split rows (%lld pieces), %.1f%% padding.\n", s.split_nnz_pct,
                  static_cast<long long>(i.n_split_rows), static_cast<long long>(i.n_partials), s.pad_pct);
+    flex_kernel_info ki{};
+    if (flex_plan_kernel_info(plan, &ki) == FLEX_OK)  // ≙ "Kernel %s:  %d regs,  %zd local,  %zd B shared." (flex.cu:4938-4940)
+        std::fprintf(stream, " Kernel: %d lanes per record, %d regs, %d local, %d B shared, %d waves per CU.\n", i.lanes_per_nz, ki.vgprs,
+                     ki.scratch_bytes, ki.lds_bytes, ki.waves_per_cu);
     std::fprintf(stream, " Plan self-check (device image is a partition of A's rows and nonzeros): %s.\n",
                  flex_plan_self_check(plan) == FLEX_OK ? "ok" : "FAILED");
     std::fprintf(stream, " B reuse: wave %.2f, workgroup %.2f, XCD %.2f; gather model %.1f MB, L2 model %.1f MB.\n",

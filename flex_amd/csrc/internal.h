@@ -56,6 +56,7 @@ int launch_spmm(const PlanView &v, int lanes_per_nz, bool off32, bool vec4, cons
                 hipStream_t s);
 int launch_fixup(const float *partial, const SplitRow *rows, uint32_t n_rows, int k, int ldc, float *dC,
                  hipStream_t s);
+int kernel_attributes(int lanes_per_nz, bool off32, bool vec4, hipFuncAttributes *attr, int *waves_per_cu);
 int launch_gather_rows(float *dst, const float *src, const int32_t *idx, int64_t n, int k, hipStream_t s);
 
 // host-side helpers shared by the ABI files

@@ -495,6 +495,21 @@ int flex_plan_get_stats(const flex_plan *p, flex_plan_stats *o) {
     return FLEX_OK;
 }
 
+int flex_plan_kernel_info(const flex_plan *p, flex_kernel_info *o) {
+    if (!p || !o) return FLEX_ERR_INVALID;
+    int cur = -1;
+    FLEX_HIP_TRY(hipGetDevice(&cur));
+    if (cur != p->device) FLEX_HIP_TRY(hipSetDevice(p->device));
+    hipFuncAttributes a{};
+    int waves = 0;
+    const bool vec4 = p->k % 4 == 0 && p->ldb % 4 == 0 && p->ldc % 4 == 0;
+    const int rc = kernel_attributes(p->lanes_per_nz, p->off32, vec4, &a, &waves);
+    if (cur != p->device) (void)hipSetDevice(cur);
+    if (rc) return rc;
+    *o = flex_kernel_info{a.numRegs, 0, static_cast<int32_t>(a.sharedSizeBytes), static_cast<int32_t>(a.localSizeBytes), 64 * kWavesPerBlock, waves};
+    return FLEX_OK;
+}
+
 // ≙ the reference's tiler round-trip (mat.cu:905-940: every entry of the pillar format exists exactly once,
 // the queues are contiguous): read the plan's DEVICE image back and check that it is a partition --
 // chunks tile the tasks, tasks tile the records, every record names a valid B row, every C row is written by

@@ -567,6 +567,27 @@ int launch_spmm(const PlanView &v, int lanes_per_nz, bool off32, bool vec4, cons
     }
 }
 
+// Registers / LDS / occupancy of the kernel launch_spmm would pick (≙ Kernel_Info, flex.cu:4933-4941).
+int kernel_attributes(int lanes_per_nz, bool off32, bool vec4, hipFuncAttributes *attr, int *waves_per_cu) {
+    const void *fn = nullptr;
+    if (!vec4) {
+        fn = off32 ? reinterpret_cast<const void *>(spmm_generic_kernel<true>) : reinterpret_cast<const void *>(spmm_generic_kernel<false>);
+    } else {
+        switch (lanes_per_nz) {
+            case 8: fn = off32 ? reinterpret_cast<const void *>(spmm_flat_kernel<8, true, 4, kWavesPerBlock>) : reinterpret_cast<const void *>(spmm_flat_kernel<8, false, 4, kWavesPerBlock>); break;
+            case 16: fn = off32 ? reinterpret_cast<const void *>(spmm_flat_kernel<16, true, 4, kWavesPerBlock>) : reinterpret_cast<const void *>(spmm_flat_kernel<16, false, 4, kWavesPerBlock>); break;
+            case 32: fn = off32 ? reinterpret_cast<const void *>(spmm_flat_kernel<32, true, 8, kWavesPerBlock>) : reinterpret_cast<const void *>(spmm_flat_kernel<32, false, 8, kWavesPerBlock>); break;
+            case 64: fn = off32 ? reinterpret_cast<const void *>(spmm_flat_kernel<64, true, 8, kWavesPerBlock>) : reinterpret_cast<const void *>(spmm_flat_kernel<64, false, 8, kWavesPerBlock>); break;
+            default: return FLEX_ERR_UNSUPPORTED;
+        }
+    }
+    FLEX_HIP_TRY(hipFuncGetAttributes(attr, fn));
+    int blocks = 0;
+    FLEX_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 64 * kWavesPerBlock, 0));
+    *waves_per_cu = blocks * kWavesPerBlock;
+    return FLEX_OK;
+}
+
 int launch_fixup(const float *partial, const SplitRow *rows, uint32_t n_rows, int k, int ldc, float *dC, hipStream_t s) {
     if (n_rows == 0) return FLEX_OK;
     const uint32_t nblk = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;

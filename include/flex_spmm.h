@@ -142,6 +142,17 @@ typedef struct flex_plan_stats {
 } flex_plan_stats;
 int flex_plan_get_stats(const flex_plan *plan, flex_plan_stats *out);
 
+/* ≙ Kernel_Info / GPU_Info (flex.cu:4127-4142, 4933-4941: "Kernel %s: %d regs, %zd local, %zd B shared"): what
+ * the kernel this plan launches (for 16-byte aligned dense operands) costs per wave and how many waves fit a CU. */
+typedef struct flex_kernel_info {
+    int32_t vgprs, sgprs;      /* per wave */
+    int32_t lds_bytes;         /* static LDS per workgroup */
+    int32_t scratch_bytes;     /* per lane */
+    int32_t threads_per_block; /* 256: four independent waves */
+    int32_t waves_per_cu;      /* resident waves the occupancy calculator allows */
+} flex_kernel_info;
+int flex_plan_kernel_info(const flex_plan *plan, flex_kernel_info *out);
+
 /* ≙ the tiler round-trip self-check of csr2_DiagTiling (mat.cu:905-940): reads the plan's device image back
  * and verifies that it is a partition of the work -- chunks tile the tasks, tasks tile the records, every
  * record names a valid B row, every C row is written exactly once (directly or by one split row with

@@ -411,6 +411,9 @@ def test_plan_self_check_on_every_kind_of_plan():
                      Plan(a, k, ldb=k + 32, ldc=k + 4)):
             plan.self_check()
             plan.destroy()
+    ki = Plan(a, 128).kernel_info()  # ≙ Kernel_Info (flex.cu:4933-4941)
+    assert 32 <= ki["vgprs"] <= 128 and ki["scratch_bytes"] == 0 and ki["lds_bytes"] == 8192 and ki["threads_per_block"] == 256
+    assert ki["waves_per_cu"] >= 16
     empty = flex_amd.HostCsr(np.zeros(6, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.float32), n=5)
     Plan(empty, 32).self_check()  # five empty rows: five tasks, no records
 
