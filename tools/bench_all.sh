@@ -1,0 +1,10 @@
+#!/bin/bash
+# One bench.py line (GFLOPS, roofline, hipSPARSE side by side) per BASELINE configuration that fits one GPU,
+# appended to gpurun_out/bench_lines.jsonl; copy to profiles/ to commit.
+out=${1:-gpurun_out/bench_lines.jsonl}
+: > $out
+for cfg in "pubmed 32" "pubmed 128" "flickr 32" "flickr 128" "yelp 32" "yelp 128" "reddit 32" "reddit 128" "amazon 32" "amazon 128"; do
+  set -- $cfg
+  steps=200; [ $1 = reddit ] && steps=50; [ $1 = yelp ] && steps=50; [ $1 = amazon ] && steps=10
+  timeout -k 10 600 python bench.py --workload $1 --k $2 --steps $steps --warmup 5 --no-cpu-baseline --no-copy-probe >> $out 2>> ${out%.jsonl}.err || echo "{\"failed\": \"$cfg\"}" >> $out
+done
