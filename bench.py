@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--shuffle", type=int, default=1, help="0: keep the generator's planted order (locality upper bound)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + FLEX_BENCH_DEVICE=0 rehearses the N>1 path on a one-GPU box (not a measurement)")
+    ap.add_argument("--autotune", action="store_true", help="FLEX_PLAN_AUTOTUNE: measure the column-tile width instead of trusting the degree rule (N=1)")
     ap.add_argument("--bcast", default="broadcast", choices=["broadcast", "scatter_allgather"],
                     help="how B reaches the other ranks (untimed, reported as b_bcast_ms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -86,7 +87,8 @@ def main():
              "natural": flex_amd.FLEX_ORDER_NATURAL}[args.order]
     if world == 1:
         want_stats = a.nnz <= 50_000_000  # one extra pass over the records: skipped on amazon-size inputs
-        plan = flex_amd.Plan(a, k, device=local_rank, order=order | (flex_amd.FLEX_PLAN_STATS if want_stats else 0))
+        plan = flex_amd.Plan(a, k, device=local_rank, order=order | (flex_amd.FLEX_PLAN_STATS if want_stats else 0)
+                             | (flex_amd.FLEX_PLAN_AUTOTUNE if args.autotune else 0))
         shard_nnz, shard_rows = a.nnz, a.m
         shard = None
     else:

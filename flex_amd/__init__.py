@@ -12,6 +12,7 @@ from .binding import (  # noqa: F401
     FLEX_ORDER_CLUSTER,
     FLEX_ORDER_GORDER,
     FLEX_PLAN_STATS,
+    FLEX_PLAN_AUTOTUNE,
     FlexError,
     HostCsr,
     Plan,

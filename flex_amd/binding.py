@@ -22,6 +22,7 @@ FLEX_ORDER_RCM = 1
 FLEX_ORDER_CLUSTER = 2
 FLEX_ORDER_GORDER = 3
 FLEX_PLAN_STATS = 0x100
+FLEX_PLAN_AUTOTUNE = 0x200
 
 
 class FlexError(RuntimeError):

@@ -145,8 +145,10 @@ void collect_stats(flex_plan *p, const std::vector<uint2> &rec, const std::vecto
 
 // Rows [r0,r1) of A.  col_map: B row read by column c (NULL = c).  dst_map: C row
 // written by row r (NULL = r - r0, i.e. slice-local).
+// sched_cache (or NULL): holds the row schedule once it has been computed, so that several candidate plans of
+// one matrix (autotune) order it only once.  force_G (or 0): lanes per record instead of the degree rule.
 int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const int32_t *col_map,
-               const int32_t *dst_map, unsigned flags) {
+               const int32_t *dst_map, unsigned flags, std::vector<uint32_t> *sched_cache = nullptr, int force_G = 0) {
     const int32_t m = r1 - r0;
     const int k = p->k;
     const unsigned order = flags & FLEX_ORDER_MASK;
@@ -165,7 +167,9 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     const double avg_deg = m > 0 ? static_cast<double>(A->rowPtr[r1] - A->rowPtr[r0]) / m : 0.0;
     int G = 8;
     while (4 * G < k && G < 64) G <<= 1;
-    if (const long g_env = env_long("FLEX_LANES", 0); g_env == 8 || g_env == 16 || g_env == 32 || g_env == 64) {
+    if (force_G) {
+        G = std::min(G, force_G);
+    } else if (const long g_env = env_long("FLEX_LANES", 0); g_env == 8 || g_env == 16 || g_env == 32 || g_env == 64) {
         G = std::min<int>(G, static_cast<int>(g_env));  // tuning experiments
     } else {
         G = std::min(G, 32);  // k = 256 as two 128-column tiles beats one 256-column tile on every shape measured
@@ -176,13 +180,19 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     p->off32 = static_cast<uint64_t>(A->n) * static_cast<uint64_t>(p->ldb) * 4u <= (uint64_t(1) << 32);
 
     // schedule: sched[i] = row of A processed i-th
-    std::vector<uint32_t> sched(m);
-    if (order != FLEX_ORDER_NATURAL) {
+    std::vector<uint32_t> sched_local;
+    std::vector<uint32_t> &sched = sched_cache ? *sched_cache : sched_local;
+    if (sched_cache && sched.size() == static_cast<size_t>(m) && m > 0) {
+        // computed by an earlier candidate of the same matrix
+    } else if (sched.assign(static_cast<size_t>(m), 0u); order != FLEX_ORDER_NATURAL) {
         std::vector<uint32_t> rank;
         int rc = order == FLEX_ORDER_RCM       ? order_rcm_host(m, A->rowPtr, A->col, rank)
                  : order == FLEX_ORDER_CLUSTER ? order_cluster_host(m, A->rowPtr, A->col, rank)
                                                : order_gorder_host(m, A->rowPtr, A->col, 3, rank);
-        if (rc) return rc;
+        if (rc) {
+            sched.clear();
+            return rc;
+        }
         for (int32_t r = 0; r < m; ++r) sched[rank[r]] = static_cast<uint32_t>(r);
     } else {
         std::iota(sched.begin(), sched.end(), static_cast<uint32_t>(r0));
@@ -359,6 +369,74 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
 
 }  // namespace
 
+extern "C" int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream);
+
+namespace {
+
+// FLEX_PLAN_AUTOTUNE: the degree rule picks the column-tile width G from two thresholds measured on a handful of
+// shapes; this measures instead.  The neighbouring widths are planned too (same row schedule, computed once),
+// each candidate is timed on zero-filled operands of the real size (what a gather costs depends on its address,
+// not on the value), and the fastest plan is kept.  Costs two extra plans and 2 * 4*(n*ldb + m*ldc) bytes for the
+// duration of the call.
+int autotune(flex_plan **pp, const flex_csr *A, int32_t r0, int32_t r1, const int32_t *col_map, const int32_t *dst_map,
+             unsigned flags, std::vector<uint32_t> &sched_cache) {
+    flex_plan *best = *pp;
+    if (best->m == 0 || best->k % 4 != 0 || best->ldb % 4 != 0 || best->ldc % 4 != 0) return FLEX_OK;
+    int g_max = 8;
+    while (4 * g_max < best->k && g_max < 32) g_max <<= 1;
+    float *dB = nullptr, *dC = nullptr;
+    const size_t b_bytes = static_cast<size_t>(best->n) * best->ldb * sizeof(float);
+    const size_t c_bytes = static_cast<size_t>(best->c_rows) * best->ldc * sizeof(float);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = FLEX_OK;
+    auto time_plan = [&](flex_plan *q, double *us) {
+        for (int i = 0; i < 2 && !rc; ++i) rc = flex_spmm(q, dB, dC, nullptr);
+        if (!rc && hipEventRecord(e0, nullptr) != hipSuccess) rc = FLEX_ERR_HIP;
+        for (int i = 0; i < 5 && !rc; ++i) rc = flex_spmm(q, dB, dC, nullptr);
+        float ms = 0.f;
+        if (!rc && (hipEventRecord(e1, nullptr) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                    hipEventElapsedTime(&ms, e0, e1) != hipSuccess))
+            rc = FLEX_ERR_HIP;
+        *us = ms * 1e3 / 5;
+    };
+    if (hipMalloc(reinterpret_cast<void **>(&dB), std::max<size_t>(b_bytes, 16)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&dC), std::max<size_t>(c_bytes, 16)) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(dB);
+        (void)hipFree(dC);
+        return FLEX_OK;  // no room to measure: keep the rule's choice
+    }
+    if (hipMemset(dB, 0, std::max<size_t>(b_bytes, 16)) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        rc = FLEX_ERR_HIP;
+    double best_us = 0.0;
+    if (!rc) time_plan(best, &best_us);
+    for (int g : {best->lanes_per_nz / 2, best->lanes_per_nz * 2}) {
+        if (rc || g < 8 || g > g_max || g == (*pp)->lanes_per_nz) continue;
+        flex_plan *q = new (std::nothrow) flex_plan();
+        if (!q) break;
+        q->m = best->m; q->n = best->n; q->k = best->k; q->device = best->device;
+        q->ldb = best->ldb; q->ldc = best->ldc; q->nnz = best->nnz;
+        double us = 0.0;
+        int rq = build_plan(q, A, r0, r1, col_map, dst_map, flags, &sched_cache, g);
+        if (rq == FLEX_OK && hipDeviceSynchronize() != hipSuccess) rq = FLEX_ERR_HIP;
+        if (rq == FLEX_OK) time_plan(q, &us);
+        if (rq == FLEX_OK && !rc && us < best_us) {
+            std::swap(best, q);
+            best_us = us;
+        }
+        free_plan_device(q);
+        delete q;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(dB);
+    (void)hipFree(dC);
+    *pp = best;
+    return rc;
+}
+
+}  // namespace
+
 extern "C" {
 
 static int create_common(flex_plan **out, const flex_csr *hostA, int64_t row_begin, int64_t row_end,
@@ -371,7 +449,7 @@ static int create_common(flex_plan **out, const flex_csr *hostA, int64_t row_beg
     if (ldc == 0) ldc = k;
     if (ldb < k || ldc < k) return FLEX_ERR_INVALID;
     const unsigned order = flags & FLEX_ORDER_MASK;
-    if (order > FLEX_ORDER_GORDER || (flags & ~(FLEX_ORDER_MASK | FLEX_PLAN_STATS))) return FLEX_ERR_INVALID;
+    if (order > FLEX_ORDER_GORDER || (flags & ~(FLEX_ORDER_MASK | FLEX_PLAN_STATS | FLEX_PLAN_AUTOTUNE))) return FLEX_ERR_INVALID;
     int rc = validate_csr(hostA);
     if (rc) return rc;
     if (hostA->m >= INT32_MAX) return FLEX_ERR_UNSUPPORTED;
@@ -395,8 +473,12 @@ static int create_common(flex_plan **out, const flex_csr *hostA, int64_t row_beg
     p->ldc = ldc;
     p->nnz = static_cast<int64_t>(hostA->rowPtr[row_end]) - hostA->rowPtr[row_begin];
     p->device = device;
+    std::vector<uint32_t> sched_cache;
+    const bool tune = (flags & FLEX_PLAN_AUTOTUNE) != 0;
     try {
-        rc = build_plan(p, hostA, static_cast<int32_t>(row_begin), static_cast<int32_t>(row_end), col_map, dst_map, flags);
+        rc = build_plan(p, hostA, static_cast<int32_t>(row_begin), static_cast<int32_t>(row_end), col_map, dst_map, flags,
+                        tune ? &sched_cache : nullptr);
+        if (rc == FLEX_OK && tune) rc = autotune(&p, hostA, static_cast<int32_t>(row_begin), static_cast<int32_t>(row_end), col_map, dst_map, flags, sched_cache);
     } catch (const std::bad_alloc &) {  // nothing crosses the C ABI as an exception
         rc = FLEX_ERR_NOMEM;
     } catch (...) {

@@ -63,6 +63,10 @@ typedef struct flex_plan flex_plan;
 #define FLEX_ORDER_GORDER 3u  /* rows scheduled in Gorder(window 3) order (≙ DataLoaderGorder, DataLoader.cu:789-857) */
 #define FLEX_ORDER_MASK 0xFu
 #define FLEX_PLAN_STATS 0x100u /* also collect flex_plan_stats while planning (one extra pass over the records) */
+#define FLEX_PLAN_AUTOTUNE 0x200u /* measure instead of trusting the degree rule: plan the neighbouring column-tile
+                                     widths too (same row schedule), time each on zero-filled operands of the real
+                                     size, keep the fastest.  Costs two extra plans and, for the duration of the call,
+                                     device memory for one B and one C */
 
 /* ≙ Mat::Mat + csr2_DiagTiling + alpha_transfer (mat.cu:7-31, 680-942, 268-293):
  * builds the row-panel plan for `hostA` and uploads it to `device`.  The reference's

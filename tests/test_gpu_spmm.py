@@ -619,3 +619,17 @@ def test_two_plans_on_two_streams_concurrently():
         p2.spmm(d2.data_ptr(), c2.data_ptr(), s2.cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(c1.cpu().numpy(), ref1) and np.array_equal(c2.cpu().numpy(), ref2)
+
+
+def test_autotuned_plan_is_correct_and_no_slower_choice_is_kept():
+    """FLEX_PLAN_AUTOTUNE plans the neighbouring column-tile widths as well and keeps the fastest: whatever it keeps
+    must pass resCheck and the self-check, statistics must describe the kept plan, and odd k (generic kernel) is a no-op."""
+    from flex_amd import FLEX_PLAN_AUTOTUNE, FLEX_PLAN_STATS
+    for deg, k in ((8, 128), (40, 128), (40, 32), (8, 100), (30, 7)):
+        a = random_csr(6000, 6000, deg, seed=81, long_rows={9: 5000})
+        B = random_B(6000, k, 5)
+        p = Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER | FLEX_PLAN_AUTOTUNE | FLEX_PLAN_STATS)
+        info, st = p.info(), p.stats()
+        assert info["lanes_per_nz"] in (8, 16, 32) and st["records"] >= a.nnz
+        p.self_check()
+        assert_matches_oracle(a, B, run_plan(p, B))
