@@ -456,7 +456,7 @@ def test_plan_stats_reuse_and_imbalance_report():
     with pytest.raises(FlexError):
         Plan(a, 64).stats()
     with pytest.raises(FlexError):
-        Plan(a, 64, order=0x200)
+        Plan(a, 64, order=0x400)
 
 
 def test_hbm_probe_reports_a_plausible_bandwidth():

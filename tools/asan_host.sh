@@ -11,6 +11,7 @@ namespace flex {  // no device code in this build: launches report "unsupported"
 int launch_spmm(const PlanView &, int, bool, bool, const float *, float *, hipStream_t) { return FLEX_ERR_UNSUPPORTED; }
 int launch_fixup(const float *, const SplitRow *, uint32_t, int, int, float *, hipStream_t) { return FLEX_ERR_UNSUPPORTED; }
 int launch_gather_rows(float *, const float *, const int32_t *, int64_t, int, hipStream_t) { return FLEX_ERR_UNSUPPORTED; }
+int kernel_attributes(int, bool, bool, hipFuncAttributes *, int *) { return FLEX_ERR_UNSUPPORTED; }
 }
 extern "C" int flex_hbm_probe(int, int64_t, int, int, double *, double *) { return FLEX_ERR_UNSUPPORTED; }
 CPP
@@ -21,4 +22,4 @@ g++ -std=c++20 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fno-
 echo "built $out/libflex_spmm.so"
 FLEX_TEST_LIB=$out/libflex_spmm.so LD_PRELOAD=$(g++ -print-file-name=libasan.so):$(g++ -print-file-name=libubsan.so) \
   ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
-  python -m pytest tests -x -q -m "not gpu" -k "not multigpu and not header and not exports and not no_cpu" "$@"
+  python -m pytest tests -x -q -m "not gpu" -k "not multigpu and not header and not exports and not no_cpu and not conv_binary" "$@"
