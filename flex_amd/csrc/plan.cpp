@@ -3,10 +3,12 @@
 // Replaces Mat::Mat / csr2_DiagTiling / alpha_transfer / launch_prep /
 // alpha_freeMatGPU (mat.cu:7-41, 268-293, 680-942; mat.cuh:184-193).  The
 // reference re-cuts A into diagonal "pillars" with per-SM queues and marks most
-// rows for atomicAdd; here the plan is a *schedule*: rows (optionally in RCM
-// order) are packed into per-wave runs of about equal nonzero count, rows longer
-// than two wave budgets are cut into chunks that write k-wide partial sums, and
-// column ids are pre-multiplied into B-row byte offsets.  Columns always refer to
+// rows for atomicAdd; here the plan is a *schedule*: rows (in the given, RCM,
+// community or Gorder order) are packed into per-wave chunks of about equal cost,
+// rows longer than one chunk budget are cut into pieces that write k-wide partial
+// sums (combined in piece order inside the launch), the chunk table is cut into
+// eight cost-balanced XCD slices, and column ids are pre-multiplied into B-row
+// byte offsets.  Columns always refer to
 // the ORIGINAL B, rows always write the ORIGINAL C row, so no permuteX pass and
 // no shadow copy of B exist (flex.cu:276-289, mat.cu:287-290).
 #include <algorithm>
@@ -198,7 +200,7 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
         std::iota(sched.begin(), sched.end(), static_cast<uint32_t>(r0));
     }
 
-    // wave budget in nonzeros; rows longer than 2 budgets are cut into chunks
+    // chunk budget in records; rows longer than one budget are cut into pieces
     // chunk budget: short chunks keep the dispatcher's load balancing fine-grained on low-degree
     // graphs (flickr: best at ~96 records), long ones amortise the per-chunk descriptor chain on
     // high-degree graphs (reddit: best at >= 256).  Measured on MI355X, DESIGN.md 3.3.
