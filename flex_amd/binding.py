@@ -61,6 +61,12 @@ class _PlanStats(C.Structure):  # flex_plan_stats
                 ("split_nnz_pct", C.c_double), ("pad_pct", C.c_double), ("n_workgroups", C.c_int64)]
 
 
+class _PlanDesc(C.Structure):  # flex_plan_desc
+    _fields_ = [("struct_size", C.c_size_t), ("A", C.POINTER(_Csr)), ("k", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int),
+                ("device", C.c_int), ("flags", C.c_uint), ("row_begin", C.c_int64), ("row_end", C.c_int64),
+                ("col_map", C.c_void_p), ("row_map", C.c_void_p)]
+
+
 class _KernelInfo(C.Structure):  # flex_kernel_info
     _fields_ = [("vgprs", C.c_int32), ("sgprs", C.c_int32), ("lds_bytes", C.c_int32), ("scratch_bytes", C.c_int32),
                 ("threads_per_block", C.c_int32), ("waves_per_cu", C.c_int32)]
@@ -75,7 +81,7 @@ class _SynthParams(C.Structure):  # flex_synth_params
 
 # every symbol include/flex_spmm.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = [
-    "flex_plan_create", "flex_plan_create_ld", "flex_plan_create_mapped", "flex_plan_create_rows", "flex_spmm",
+    "flex_plan_create", "flex_plan_create_ex", "flex_plan_create_ld", "flex_plan_create_mapped", "flex_plan_create_rows", "flex_spmm",
     "flex_plan_destroy", "flex_plan_get_info", "flex_plan_get_stats", "flex_plan_self_check", "flex_plan_kernel_info", "flex_hbm_probe", "flex_gather_rows", "flex_csv_load", "flex_mtx_load",
     "flex_csv_save", "flex_csr_save_bin", "flex_csr_load_bin", "flex_csr_fingerprint", "flex_perm_save", "flex_perm_load",
     "flex_host_csr_free", "flex_fill_dense_rand", "flex_order_rcm", "flex_order_cluster", "flex_order_gorder", "flex_perm_csr",
@@ -115,6 +121,7 @@ def lib():
         L = C.CDLL(_SO)
         vp, i64, i32, u32 = C.c_void_p, C.c_int64, C.c_int, C.c_uint
         L.flex_plan_create.argtypes = [C.POINTER(vp), C.POINTER(_Csr), i32, i32, u32]
+        L.flex_plan_create_ex.argtypes = [C.POINTER(vp), C.POINTER(_PlanDesc)]
         L.flex_plan_create_ld.argtypes = [C.POINTER(vp), C.POINTER(_Csr), i32, i32, i32, i32, u32]
         L.flex_plan_create_mapped.argtypes = [C.POINTER(vp), C.POINTER(_Csr), vp, i32, i32, u32]
         L.flex_plan_create_rows.argtypes = [C.POINTER(vp), C.POINTER(_Csr), i64, i64, vp, i32, i32, u32]
@@ -340,7 +347,17 @@ class Plan:
         self._keep = (a, vo_mp, col_map)
         v = a.view()
         L = lib()
-        if rows is not None:
+        if (ldb is not None or ldc is not None) and (rows is not None or vo_mp is not None):
+            # a combination the named entry points do not cover: the general one
+            cm = None if col_map is None else np.ascontiguousarray(col_map, dtype=np.int32)
+            vm = None if vo_mp is None else np.ascontiguousarray(vo_mp, dtype=np.int32)
+            self._keep = (a, cm, vm)
+            d = _PlanDesc(C.sizeof(_PlanDesc), C.pointer(v), k, ldb or 0, ldc or 0, device, order,
+                          0 if rows is None else int(rows[0]), 0 if rows is None else int(rows[1]),
+                          (cm if cm is not None else vm).ctypes.data if (cm is not None or vm is not None) else None,
+                          None if vm is None else vm.ctypes.data)
+            rc = L.flex_plan_create_ex(C.byref(self._h), C.byref(d))
+        elif rows is not None:
             cm = None if col_map is None else np.ascontiguousarray(col_map, dtype=np.int32)
             self._keep = (a, cm)
             rc = L.flex_plan_create_rows(C.byref(self._h), C.byref(v), int(rows[0]), int(rows[1]),

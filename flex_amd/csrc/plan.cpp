@@ -522,6 +522,15 @@ int flex_plan_create_rows(flex_plan **out, const flex_csr *hostA, int64_t row_be
     return create_common(out, hostA, row_begin, row_end, col_map, nullptr, k, device, flags);
 }
 
+int flex_plan_create_ex(flex_plan **out, const flex_plan_desc *d) {
+    if (!d || !d->A || d->struct_size != sizeof(flex_plan_desc)) return FLEX_ERR_INVALID;
+    const bool all_rows = d->row_begin == 0 && d->row_end == 0;
+    const int64_t r0 = d->row_begin, r1 = all_rows ? d->A->m : d->row_end;
+    if (d->row_map && (!all_rows || d->A->m != d->A->n)) return FLEX_ERR_INVALID;  // a row map renames ALL rows of a graph
+    if (!all_rows && (d->flags & FLEX_ORDER_MASK) != FLEX_ORDER_NATURAL) return FLEX_ERR_INVALID;  // reorder first, then shard
+    return create_common(out, d->A, r0, r1, d->col_map, d->row_map, d->k, d->device, d->flags, d->ldb, d->ldc);
+}
+
 int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream) {
     if (!p) return FLEX_ERR_INVALID;
     if (p->m == 0) return FLEX_OK;

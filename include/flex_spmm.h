@@ -97,6 +97,23 @@ int flex_plan_create_mapped(flex_plan **out, const flex_csr *hostA, const int32_
 int flex_plan_create_rows(flex_plan **out, const flex_csr *hostA, int64_t row_begin, int64_t row_end,
                           const int32_t *col_map, int k, int device, unsigned flags);
 
+/* Every option of the four entry points above in one call (they are thin wrappers over it), for the combinations
+ * they do not name -- e.g. a row shard of a reordered matrix over padded storage.  Zero-initialise, set
+ * struct_size = sizeof(flex_plan_desc), fill what is needed:
+ *   row_begin/row_end  0/0 = all rows; otherwise the shard [row_begin,row_end) (flags must be FLEX_ORDER_NATURAL)
+ *   col_map            column c of A reads B row col_map[c] (NULL = c)
+ *   row_map            row r of A writes C row row_map[r] (NULL = r - row_begin); all rows only, A square
+ *   ldb/ldc            row strides of B and C in floats (0 = k) */
+typedef struct flex_plan_desc {
+    size_t struct_size;
+    const flex_csr *A;
+    int k, ldb, ldc, device;
+    unsigned flags;
+    int64_t row_begin, row_end;
+    const int32_t *col_map, *row_map;
+} flex_plan_desc;
+int flex_plan_create_ex(flex_plan **out, const flex_plan_desc *desc);
+
 /* ≙ launch_prep + cudaMemset(C) + kernel<<<>>> (mat.cu:32-41, flex.cu:5057-5059).
  * dB: n x k row-major device fp32; dC: m x k row-major device fp32, fully overwritten
  * (alpha=1, beta=0 as in cuSpmm, flex.cu:5728-5729).  Asynchronous on `stream`;

@@ -633,3 +633,46 @@ def test_autotuned_plan_is_correct_and_no_slower_choice_is_kept():
         assert info["lanes_per_nz"] in (8, 16, 32) and st["records"] >= a.nnz
         p.self_check()
         assert_matches_oracle(a, B, run_plan(p, B))
+
+
+def test_general_entry_point_covers_combinations():
+    """flex_plan_create_ex: a reordered (mapped) matrix and a row shard of it, both over padded storage -- the
+    combinations the named entry points do not offer."""
+    import torch
+    a = random_csr(2400, 2400, 15, seed=91, long_rows={6: 2000})
+    rank = flex_amd.order_rcm(a)
+    vo, ap = flex_amd.perm_csr(a, rank)
+    k, ldb, ldc = 100, 128, 104
+    rng = np.random.default_rng(3)
+    Bs = rng.uniform(-1, 1, size=(a.n, ldb)).astype(np.float32)
+    Bd = torch.from_numpy(Bs).cuda()
+    gold = oracle.spmm(a.rowPtr, a.col, a.vals, np.ascontiguousarray(Bs[:, :k]), nthreads=4)
+    # mapped + strided: B and C in ORIGINAL order although the plan is built from the permuted CSR
+    p = Plan(ap, k, vo_mp=vo, ldb=ldb, ldc=ldc)
+    p.self_check()
+    Cd = torch.full((a.m, ldc), 9.0, dtype=torch.float32, device="cuda")
+    p.spmm(Bd.data_ptr(), Cd.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    C = Cd.cpu().numpy()
+    assert np.all(C[:, k:] == 9.0) and oracle.rescheck(gold, np.ascontiguousarray(C[:, :k]), a.rowPtr)[0] == 0
+    # two row shards of the permuted matrix, strided: slice-local C rows, original B
+    got = np.zeros_like(gold)
+    for r0, r1 in ((0, 1000), (1000, 2400)):
+        ps = Plan(ap, k, rows=(r0, r1), col_map=vo, ldb=ldb, ldc=ldc)
+        ps.self_check()
+        Cs = torch.full((r1 - r0, ldc), 9.0, dtype=torch.float32, device="cuda")
+        ps.spmm(Bd.data_ptr(), Cs.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        Csh = Cs.cpu().numpy()
+        assert np.all(Csh[:, k:] == 9.0)
+        got[vo[r0:r1]] = Csh[:, :k]
+    assert oracle.rescheck(gold, got, a.rowPtr)[0] == 0
+    # argument checks of the descriptor form
+    import ctypes as C
+    from flex_amd import binding
+    h = C.c_void_p()
+    v = a.view()
+    bad = binding._PlanDesc(8, C.pointer(v), k, 0, 0, 0, 0, 0, 0, None, None)  # wrong struct_size
+    assert binding.lib().flex_plan_create_ex(C.byref(h), C.byref(bad)) == -1
+    shard_ordered = binding._PlanDesc(C.sizeof(binding._PlanDesc), C.pointer(v), k, 0, 0, 0, flex_amd.FLEX_ORDER_RCM, 0, 100, None, None)
+    assert binding.lib().flex_plan_create_ex(C.byref(h), C.byref(shard_ordered)) == -1  # reorder first, then shard
