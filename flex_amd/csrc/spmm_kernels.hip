@@ -314,7 +314,9 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
         }
     }
 #ifdef FLEX_ABL_NOFLUSH
-    if (nt > 0) { ti = nt - 1; flush(0xFFFFFFFEu); }  // pos != the ~0 sentinel, or the do-while never ends
+    // pos != the ~0 sentinel, or the do-while never ends; a piece's task is reduced below, not flushed (its dst is a
+    // partial-slot id, not a C row)
+    if (nt > 0 && !piece) { ti = nt - 1; flush(0xFFFFFFFEu); }
 #endif
     if (piece) {
         const RowOut<G> o = reduce_row<G>(acc);
