@@ -9,9 +9,12 @@
 //   * A operand: lane l holds L[row l&31][k = 2kk + (l>>5)], B operand: Wp[k = 2kk + (l>>5)][col l&31]
 //     (cdna guide, 'FP32-input MFMA'); C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5);
 //   * the result is bit-for-bit a k-ordered fmaf chain per output element.
-// Replaces rocBLAS SGEMM for dim <= 128 (rocBLAS: 48-62 us on the flickr shape, n = 89250, dim = cp = 128).
+// Replaces rocBLAS SGEMM for dim <= 256 (n x 128 x 128: flickr shape 37-42 us against rocBLAS 37-65, reddit shape
+// 87-93 us against 186-207).  Timing-only ablations of this kernel on the flickr shape: without its stores 34 us,
+// without its MFMAs 18-22 us, i.e. the data movement and the matrix pipe still add up instead of overlapping.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 
 namespace flex_axw_detail {
@@ -24,19 +27,26 @@ constexpr int kPad = 4;  // floats: keeps 16-byte alignment of a tile row for ds
 
 // Order of the k sum: MFMA step s takes two k values, one per wave half h = lane>>5.  Steps 2m and 2m+1 use
 // k = 4m+2h and 4m+2h+1, so a lane's A operands of both steps are ONE 8-byte LDS read (L[row][4m+2h .. +1]) and,
-// with Wp stored in LDS as k-pairs ([k/2][col][k&1]), so are its B operands.
+// with W stored in LDS as k-pairs ([k/2][col][k&1]), so are its B operands.
 // Every panel is a FULL 32 rows: the last one starts at n-32 and overlaps its predecessor (both write the same
 // values to the shared rows), so neither the loads nor the stores carry a row guard.  Requires n >= 32.
+// A panel is staged in k-slabs of 64 floats (8.5 KiB per wave), which is what lets EIGHT waves share one copy of W
+// in LDS: two waves per SIMD, so one wave's staging and stores hide behind the other's MFMAs.  Waves w and w+4 of
+// a workgroup share a SIMD; panels are dealt so that the second wave of a SIMD gets work only after every SIMD
+// has one (a short launch otherwise loads some SIMDs with 4 panels and others with 2).
+constexpr int kSlab = 64;                    // floats of k per staged slab
+constexpr int kSlabLoads = kSlab / 8;        // float4 per lane and slab: 32 rows x 16 float4 / 64 lanes
+constexpr int kWaves = 8;
+
 template <int NT>  // 32-column output tiles per wave and pass (1..4)
-__global__ __launch_bounds__(256) void axw_gemm_kernel(const float *__restrict__ L, const float *__restrict__ Wp,
-                                                       float *__restrict__ Out, int n, int dim, int cp, int col0) {
+__global__ __launch_bounds__(64 * kWaves) void axw_gemm_kernel(const float *__restrict__ L, const float *__restrict__ Wp,
+                                                               float *__restrict__ Out, int n, int dim, int cp, int col0) {
     extern __shared__ float smem[];
-    constexpr int WC = 32 * NT;   // columns of this pass
-    constexpr int kLoads = 16;    // float4 per lane of one staged panel at dim = 128 (32 rows x 32 float4 / 64 lanes)
+    constexpr int WC = 32 * NT;          // columns of this pass
+    constexpr int xs = kSlab + kPad;     // floats per staged row
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int xs = dim + kPad;  // floats per staged row
-    float *sW = smem;           // [dim/2][WC][2]
+    float *sW = smem;                    // [dim/2][WC][2]
     float *sX = smem + dim * WC + wave * (kRowsPerWave * xs);
 
     // Wp[:, col0 : col0+WC] -> LDS as k-pairs, once per workgroup
@@ -47,77 +57,81 @@ __global__ __launch_bounds__(256) void axw_gemm_kernel(const float *__restrict__
         d[0] = w.x; d[2] = w.y; d[4] = w.z; d[6] = w.w;
     }
 
-    // where this lane's 16 float4 of a panel come from (element offset inside the panel) and go to (LDS); the
-    // division by dim/4 happens once here, not per panel.  Slots past the panel (dim < 128) repeat its last element.
-    const int d4 = dim / 4;
-    int src_off[kLoads], lds_off[kLoads];
+    // this lane's 8 float4 of a slab: row and column inside the slab (fixed), LDS slot (fixed)
+    int row_i[kSlabLoads], col_i[kSlabLoads], lds_off[kSlabLoads];
 #pragma unroll
-    for (int i = 0; i < kLoads; ++i) {
-        const int f = min(i * 64 + lane, kRowsPerWave * d4 - 1), row = f / d4, c4 = f % d4;
-        src_off[i] = row * dim + c4 * 4;
-        lds_off[i] = row * xs + c4 * 4;
+    for (int i = 0; i < kSlabLoads; ++i) {
+        const int f = i * 64 + lane;
+        row_i[i] = f / (kSlab / 4);
+        col_i[i] = (f % (kSlab / 4)) * 4;
+        lds_off[i] = row_i[i] * xs + col_i[i];
     }
     const int n_panels = (n + kRowsPerWave - 1) / kRowsPerWave;
+    const int n_slabs = (dim + kSlab - 1) / kSlab;
     auto panel_row = [&](int pnl) { return min(min(pnl, n_panels - 1) * kRowsPerWave, n - kRowsPerWave); };
-
-    int panel = blockIdx.x * 4 + wave;
-    f32x4 pre[kLoads];  // the NEXT panel, in flight while this one is multiplied
-    {
-        const float *src = L + static_cast<size_t>(panel_row(panel)) * dim;
+    // unit u = (panel, slab) in the order this wave meets them; loads of a slab's tail past dim re-read the row's last float4
+    const int first_panel = wave < 4 ? blockIdx.x * 4 + wave : gridDim.x * 4 + blockIdx.x * 4 + (wave - 4);
+    const int panel_step = gridDim.x * kWaves;
+    f32x4 pre[kSlabLoads];  // the NEXT slab, in flight while this one is multiplied
+    auto fetch = [&](int pnl, int slab) {
+        const float *src = L + static_cast<size_t>(panel_row(pnl)) * dim;
+        const int k0 = slab * kSlab;
 #pragma unroll
-        for (int i = 0; i < kLoads; ++i) pre[i] = *reinterpret_cast<const f32x4 *>(src + src_off[i]);
-    }
+        for (int i = 0; i < kSlabLoads; ++i)
+            pre[i] = *reinterpret_cast<const f32x4 *>(src + static_cast<size_t>(row_i[i]) * dim + min(k0 + col_i[i], dim - 4));
+    };
+    fetch(first_panel, 0);
     __syncthreads();  // Wp staged (the only barrier: the panel tiles are private to a wave)
 
     const float *ap = sX + (lane & 31) * xs + 2 * (lane >> 5);
     const float *bp = sW + (lane >> 5) * (2 * WC) + (lane & 31) * 2;
-    for (; panel < n_panels; panel += gridDim.x * 4) {
+    for (int panel = first_panel; panel < n_panels; panel += panel_step) {
         const int r0 = panel_row(panel);
-#pragma unroll
-        for (int i = 0; i < kLoads; ++i) *reinterpret_cast<f32x4 *>(sX + lds_off[i]) = pre[i];
-        {
-            const float *src = L + static_cast<size_t>(panel_row(panel + gridDim.x * 4)) * dim;
-#pragma unroll
-            for (int i = 0; i < kLoads; ++i) pre[i] = *reinterpret_cast<const f32x4 *>(src + src_off[i]);
-        }
         f32x16 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-        // operands of step pair m+1 are read from the LDS while the 2*NT MFMAs of pair m issue (one wave per SIMD:
-        // nobody else hides the LDS latency); the sched_barriers keep the reads ABOVE the MFMAs they overlap with
-        // (the scheduler sinks them next to their use otherwise)
-        auto lda = [&](int m) { return *reinterpret_cast<const float2 *>(ap + 4 * m); };
-        auto ldb = [&](int m, int t) { return *reinterpret_cast<const float2 *>(bp + (2 * m) * (2 * WC) + t * 64); };
-        float2 a0 = lda(0), b0[NT], a1, b1[NT];
+        for (int slab = 0; slab < n_slabs; ++slab) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) b0[t] = ldb(0, t);
-        int m = 0;
-        for (; m + 2 <= d4; m += 2) {
-            a1 = lda(m + 1);
+            for (int i = 0; i < kSlabLoads; ++i) *reinterpret_cast<f32x4 *>(sX + lds_off[i]) = pre[i];
+            if (slab + 1 < n_slabs) fetch(panel, slab + 1);  // wave-uniform
+            else fetch(panel + panel_step, 0);
+            const int d4 = min(kSlab, dim - slab * kSlab) / 4;  // k-quads in this slab
+            const float *bs = bp + (slab * (kSlab / 2)) * (2 * WC);
+            // operands of step pair m+1 are read from the LDS while the 2*NT MFMAs of pair m issue; the sched_barriers
+            // keep the reads ABOVE the MFMAs they overlap with (the scheduler sinks them next to their use otherwise)
+            auto lda = [&](int m) { return *reinterpret_cast<const float2 *>(ap + 4 * m); };
+            auto ldb = [&](int m, int t) { return *reinterpret_cast<const float2 *>(bs + (2 * m) * (2 * WC) + t * 64); };
+            float2 a0 = lda(0), b0[NT], a1, b1[NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) b1[t] = ldb(m + 1, t);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int t = 0; t < NT; ++t) b0[t] = ldb(0, t);
+            int m = 0;
+            for (; m + 2 <= d4; m += 2) {
+                a1 = lda(m + 1);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0[t].x, acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) b1[t] = ldb(m + 1, t);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0[t].y, acc[t], 0, 0, 0);
-            const int mn = min(m + 2, d4 - 1);  // the last pair re-reads a valid slot instead of branching
-            a0 = lda(mn);
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0[t].x, acc[t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) b0[t] = ldb(mn, t);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0[t].y, acc[t], 0, 0, 0);
+                const int mn = min(m + 2, d4 - 1);  // the last pair re-reads a valid slot instead of branching
+                a0 = lda(mn);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1[t].x, acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) b0[t] = ldb(mn, t);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1[t].y, acc[t], 0, 0, 0);
-        }
-        if (m < d4) {  // d4 odd: one pair left, already in a0 / b0
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1[t].x, acc[t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0[t].x, acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1[t].y, acc[t], 0, 0, 0);
+            }
+            if (m < d4) {  // odd number of k-quads: one pair left, already in a0 / b0
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0[t].y, acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0[t].y, acc[t], 0, 0, 0);
+            }
         }
         // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
         float *dst = Out + static_cast<size_t>(r0 + 4 * (lane >> 5)) * cp + col0 + (lane & 31);
@@ -131,14 +145,16 @@ __global__ __launch_bounds__(256) void axw_gemm_kernel(const float *__restrict__
 
 }  // namespace flex_axw_detail
 
-// Out[n x cp] = L[n x dim] * Wp[dim x cp].  Requires n >= 32, dim % 4 == 0, dim <= 128, cp % 32 == 0.  Returns hipSuccess or the launch error.
+// Out[n x cp] = L[n x dim] * Wp[dim x cp].  Requires n >= 32, dim % 4 == 0, dim <= 256, cp % 32 == 0.  Returns hipSuccess or
+// the launch error.  The pass width is what keeps Wp's slice within 64 KiB of LDS: 128 columns up to dim = 128, 64 beyond.
 extern "C" hipError_t flex_axw_gemm_launch(const float *L, const float *Wp, float *Out, int n, int dim, int cp, int n_cus, hipStream_t s) {
     using namespace flex_axw_detail;
     if (n <= 0) return hipSuccess;
-    for (int col0 = 0; col0 < cp; col0 += 128) {
-        const int nt = (cp - col0 >= 128) ? 4 : (cp - col0) / 32;
-        const size_t lds = (static_cast<size_t>(dim) * 32 * nt + 4 * kRowsPerWave * (dim + kPad)) * sizeof(float);
-        const dim3 grid(static_cast<unsigned>(n_cus)), block(256);
+    const int max_cols = dim <= 128 ? 128 : 64;
+    for (int col0 = 0; col0 < cp; col0 += max_cols) {
+        const int nt = std::min(max_cols, cp - col0) / 32;
+        const size_t lds = (static_cast<size_t>(dim) * 32 * nt + kWaves * kRowsPerWave * (kSlab + kPad)) * sizeof(float);
+        const dim3 grid(static_cast<unsigned>(n_cus)), block(64 * kWaves);
         hipError_t e = hipSuccess;
         auto go = [&](auto kernel) {  // more than 64 KiB of dynamic LDS has to be asked for
             e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));

@@ -486,7 +486,7 @@ def test_every_column_tile_width_gives_the_same_answer(monkeypatch, lanes, k):
     assert_matches_oracle(a, B, run_plan(p2, B))
 
 
-@pytest.mark.parametrize("dim,c", [(32, 7), (128, 41), (16, 64), (128, 100), (64, 130), (20, 33), (12, 5), (130, 40), (256, 16)])
+@pytest.mark.parametrize("dim,c", [(32, 7), (128, 41), (16, 64), (128, 100), (64, 130), (20, 33), (12, 5), (130, 40), (256, 16), (200, 70), (256, 100), (260, 8)])
 def test_axw_both_orders_match_a_float64_reference(dim, c):
     """libflex_axw.so (≙ run1 / run2 of cusp.cu): A(XW) and (AX)W agree with each other (the reference's own
     check, DataLoader.cu:859-869) and with A @ X @ W in float64; padded columns are zero; AUTO takes the
