@@ -49,12 +49,26 @@ __global__ __launch_bounds__(64 * kWaves) void axw_gemm_kernel(const float *__re
     float *sW = smem;                    // [dim/2][WC][2]
     float *sX = smem + dim * WC + wave * (kRowsPerWave * xs);
 
-    // Wp[:, col0 : col0+WC] -> LDS as k-pairs, once per workgroup
-    for (int i = threadIdx.x; i < dim * (WC / 4); i += blockDim.x) {
-        const int kr = i / (WC / 4), c4 = i % (WC / 4);
-        const float4 w = *reinterpret_cast<const float4 *>(Wp + static_cast<size_t>(kr) * cp + col0 + c4 * 4);
-        float *d = sW + (kr >> 1) * (2 * WC) + (c4 * 4) * 2 + (kr & 1);
-        d[0] = w.x; d[2] = w.y; d[4] = w.z; d[6] = w.w;
+    // Wp[:, col0 : col0+WC] -> LDS as k-pairs, once per workgroup.  The slice is at most 64 KiB = 8 float4 per thread:
+    // all eight loads go out together (a loop of load -> wait -> write costs eight memory round trips before the
+    // first MFMA), slots past the slice re-read its last float4 and are not written.
+    {
+        const int total = dim * (WC / 4);
+        f32x4 w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = min(static_cast<int>(threadIdx.x) + j * static_cast<int>(blockDim.x), total - 1);
+            w[j] = *reinterpret_cast<const f32x4 *>(Wp + static_cast<size_t>(i / (WC / 4)) * cp + col0 + (i % (WC / 4)) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = static_cast<int>(threadIdx.x) + j * static_cast<int>(blockDim.x);
+            if (i < total) {
+                const int kr = i / (WC / 4), c4 = i % (WC / 4);
+                float *d = sW + (kr >> 1) * (2 * WC) + (c4 * 4) * 2 + (kr & 1);
+                d[0] = w[j][0]; d[2] = w[j][1]; d[4] = w[j][2]; d[6] = w[j][3];
+            }
+        }
     }
 
     // this lane's 8 float4 of a slab: row and column inside the slab (fixed), LDS slot (fixed)
