@@ -94,7 +94,7 @@ def test_shard_local_csr_uses_original_columns():
     a = flex_amd.synth_graph(n=1500, nnz=1500 + 2 * 6000, community=50, p_in=0.6, p_near=0.2, seed=3)
     B = np.random.default_rng(1).uniform(-1, 1, (a.n, 8)).astype(np.float32)
     gold = oracle.spmm(a.rowPtr, a.col, a.vals, B)
-    for world in (1, 3):
+    for world in (1, 3, 8):
         got = np.zeros_like(gold)
         for r in range(world):
             sh = flex_amd.make_shard(a, 8, r, world, order="cluster")
