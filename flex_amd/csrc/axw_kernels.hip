@@ -10,8 +10,9 @@
 //     (cdna guide, 'FP32-input MFMA'); C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5);
 //   * the result is bit-for-bit a k-ordered fmaf chain per output element.
 // Replaces rocBLAS SGEMM for dim <= 256 (n x 128 x 128: flickr shape 37-42 us against rocBLAS 37-65, reddit shape
-// 87-93 us against 186-207).  Timing-only ablations of this kernel on the flickr shape: without its stores 34 us,
-// without its MFMAs 18-22 us, i.e. the data movement and the matrix pipe still add up instead of overlapping.
+// 79-85 us against 186-207).  On the flickr shape the matrix pipe is 63 % busy (SQ_VALU_MFMA_BUSY_CYCLES): the clock
+// is ~2.0 GHz under this load, the busiest SIMDs carry 3 panels against 2.7 on average, and ~8 us of launch, W staging,
+// first fetch and last stores overlap nothing.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
