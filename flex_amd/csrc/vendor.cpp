@@ -14,6 +14,7 @@ struct flex_vendor {
     hipsparseDnMatDescr_t B = nullptr, C = nullptr;
     void *buffer = nullptr;
     float alpha = 1.0f, beta = 0.0f;
+    hipsparseSpMMAlg_t alg = HIPSPARSE_SPMM_CSR_ALG3;
 };
 
 static thread_local int g_status = 0;
@@ -45,10 +46,17 @@ int flex_vendor_spmm_destroy(flex_vendor *h) {
 
 int flex_vendor_spmm_create(flex_vendor **out, int32_t m, int32_t n, int64_t nnz, const uint32_t *d_rowPtr,
                             const uint32_t *d_col, const float *d_vals, int k, const float *dB, float *dC) {
+    return flex_vendor_spmm_create_alg(out, m, n, nnz, d_rowPtr, d_col, d_vals, k, dB, dC, 3);
+}
+
+int flex_vendor_spmm_create_alg(flex_vendor **out, int32_t m, int32_t n, int64_t nnz, const uint32_t *d_rowPtr,
+                                const uint32_t *d_col, const float *d_vals, int k, const float *dB, float *dC, int alg) {
+    if (alg < 0 || alg > 3) return -1;
     if (!out || m < 0 || n < 0 || nnz < 0 || k <= 0 || !d_rowPtr || !dC) return -1;
     *out = nullptr;
     flex_vendor *h = new (std::nothrow) flex_vendor();
     if (!h) return -2;
+    h->alg = alg == 0 ? HIPSPARSE_SPMM_ALG_DEFAULT : alg == 1 ? HIPSPARSE_SPMM_CSR_ALG1 : alg == 2 ? HIPSPARSE_SPMM_CSR_ALG2 : HIPSPARSE_SPMM_CSR_ALG3;
     VENDOR_TRY(hipsparseCreate(&h->handle));
     VENDOR_TRY(hipsparseCreateCsr(&h->A, m, n, nnz, const_cast<uint32_t *>(d_rowPtr), const_cast<uint32_t *>(d_col),
                                   const_cast<float *>(d_vals), HIPSPARSE_INDEX_32I, HIPSPARSE_INDEX_32I,
@@ -57,7 +65,7 @@ int flex_vendor_spmm_create(flex_vendor **out, int32_t m, int32_t n, int64_t nnz
     VENDOR_TRY(hipsparseCreateDnMat(&h->C, m, k, k, dC, HIP_R_32F, HIPSPARSE_ORDER_ROW));
     size_t bytes = 0;
     VENDOR_TRY(hipsparseSpMM_bufferSize(h->handle, HIPSPARSE_OPERATION_NON_TRANSPOSE, HIPSPARSE_OPERATION_NON_TRANSPOSE,
-                                        &h->alpha, h->A, h->B, &h->beta, h->C, HIP_R_32F, HIPSPARSE_SPMM_CSR_ALG3,
+                                        &h->alpha, h->A, h->B, &h->beta, h->C, HIP_R_32F, h->alg,
                                         &bytes));
     if (hipMalloc(&h->buffer, bytes ? bytes : 4) != hipSuccess) {
         flex_vendor_spmm_destroy(h);
@@ -72,7 +80,7 @@ int flex_vendor_spmm_run(flex_vendor *h, flex_vendor_stream_t stream) {
     hipsparseStatus_t st = hipsparseSetStream(h->handle, reinterpret_cast<hipStream_t>(stream));
     if (st == HIPSPARSE_STATUS_SUCCESS)
         st = hipsparseSpMM(h->handle, HIPSPARSE_OPERATION_NON_TRANSPOSE, HIPSPARSE_OPERATION_NON_TRANSPOSE, &h->alpha,
-                           h->A, h->B, &h->beta, h->C, HIP_R_32F, HIPSPARSE_SPMM_CSR_ALG3, h->buffer);
+                           h->A, h->B, &h->beta, h->C, HIP_R_32F, h->alg, h->buffer);
     if (st != HIPSPARSE_STATUS_SUCCESS) {
         g_status = static_cast<int>(st);
         return -8;

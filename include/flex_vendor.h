@@ -22,6 +22,10 @@ typedef struct ihipStream_t *flex_vendor_stream_t;
  * negative code (-3: HIP error, -8: hipSPARSE status, see flex_vendor_last_status). */
 int flex_vendor_spmm_create(flex_vendor **out, int32_t m, int32_t n, int64_t nnz, const uint32_t *d_rowPtr,
                             const uint32_t *d_col, const float *d_vals, int k, const float *dB, float *dC);
+/* Same with the algorithm named: 0 = HIPSPARSE_SPMM_ALG_DEFAULT, 1..3 = HIPSPARSE_SPMM_CSR_ALG1..3 (3 is what the
+ * reference's protocol uses; the others are for a "best of vendor" side-by-side). */
+int flex_vendor_spmm_create_alg(flex_vendor **out, int32_t m, int32_t n, int64_t nnz, const uint32_t *d_rowPtr,
+                                const uint32_t *d_col, const float *d_vals, int k, const float *dB, float *dC, int alg);
 /* one hipsparseSpMM on `stream` (the reference times 5 warm-up + 10 of these, flex.cu:5766-5789) */
 int flex_vendor_spmm_run(flex_vendor *h, flex_vendor_stream_t stream);
 int flex_vendor_spmm_destroy(flex_vendor *h);
