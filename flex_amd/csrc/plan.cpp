@@ -13,6 +13,7 @@
 // no shadow copy of B exist (flex.cu:276-289, mat.cu:287-290).
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -264,7 +265,11 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
             const uint32_t len = e1 - e0;
             const uint32_t dst = dst_map ? static_cast<uint32_t>(dst_map[r]) : r - static_cast<uint32_t>(r0);
             if (len > long_row) {
-                const uint32_t nchunk = (len + piece - 1) / piece;
+                // The last piece to arrive sums all of them with ONE wave, so a hub of 10^6 nonzeros cut into 10^4
+                // budget-sized pieces spent 0.9 ms in that sum alone (tools/probe_hub.py: 1263 us against 358 us
+                // without the hub).  At most 256 pieces per row, longer ones instead: 564 us (774 pieces: 601 us).
+                constexpr uint32_t kMaxPieces = 256;
+                const uint32_t nchunk = std::min<uint32_t>((len + piece - 1) / piece, kMaxPieces);
                 const uint32_t per = ((len + nchunk - 1) / nchunk + S - 1) / S * S;  // whole steps
                 split.push_back({dst, n_partials, 0});
                 split_nnz += len;
