@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="flickr", help="synthetic preset: flickr|reddit|amazon|yelp|ppi|pubmed")
+    ap.add_argument("--graph", default=None, help="a real graph instead of a preset: .csv (the reference's format), .mtx or .bin "
+                                                  "(e.g. tests/golden/pubmed.csv, the one data file the reference ships); strong scaling only")
     ap.add_argument("--k", type=int, default=128)
     ap.add_argument("--order", default="cluster", choices=["cluster", "rcm", "natural"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
@@ -78,7 +80,15 @@ def main():
     scale = world if args.scaling == "weak" else 1
     # ---- workload: synthetic graph with the README's shape (x N vertices and nonzeros when weak-scaling)
     t_gen = time.perf_counter()
-    a = flex_amd.synth_graph(args.workload, scale=scale, shuffle=bool(args.shuffle))
+    if args.graph:
+        if world > 1 and args.scaling != "strong":
+            raise SystemExit("--graph is one fixed matrix: use --scaling strong with more than one GPU")
+        ext = os.path.splitext(args.graph)[1].lower()
+        a = (flex_amd.mtx_load(args.graph, sort_columns=True) if ext == ".mtx" else
+             flex_amd.csr_load_bin(args.graph) if ext == ".bin" else flex_amd.csv_load(args.graph))
+        args.workload = os.path.splitext(os.path.basename(args.graph))[0] + " (file)"
+    else:
+        a = flex_amd.synth_graph(args.workload, scale=scale, shuffle=bool(args.shuffle))
     t_gen = time.perf_counter() - t_gen
 
     # ---- plan: RCM is a schedule (N=1) or an explicit permutation followed by row sharding (N>1)
@@ -175,10 +185,11 @@ def main():
             "metric": "SpMM GFLOPS (2*nnz*k/t)", "value": round(gflops, 2), "unit": "GFLOPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 6), "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "file" if args.graph else "synthetic",
             "config": {
-                "workload": f"{args.workload}-shape synthetic graph x{scale} (n={a.n}, nnz={a.nnz}), k={k}, fp32, "
-                            f"{args.order} schedule" + (f", rows sharded over {world} GPUs, B broadcast once" if world > 1 else ""),
+                "workload": (f"{args.workload} (n={a.n}, nnz={a.nnz}), k={k}, fp32, " if args.graph else
+                             f"{args.workload}-shape synthetic graph x{scale} (n={a.n}, nnz={a.nnz}), k={k}, fp32, ")
+                            + f"{args.order} schedule" + (f", rows sharded over {world} GPUs, B broadcast once" if world > 1 else ""),
                 "n": a.n, "nnz": a.nnz, "k": k, "order": args.order, "parallelism": f"row-shard x{world}",
                 "plan": {"chunks": info["n_chunks"], "tasks": info["n_tasks"], "split_rows": info["n_split_rows"],
                          "lanes_per_nz": info["lanes_per_nz"], "plan_s": round(t_plan, 3), "gen_s": round(t_gen, 3)},
