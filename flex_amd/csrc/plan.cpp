@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -154,6 +155,14 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
                const int32_t *dst_map, unsigned flags, std::vector<uint32_t> *sched_cache = nullptr, int force_G = 0) {
     const int32_t m = r1 - r0;
     const int k = p->k;
+    const bool timing = std::getenv("FLEX_PLAN_TIMING") != nullptr;  // phase times of the planner on stderr
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "plan: %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     const unsigned order = flags & FLEX_ORDER_MASK;
     if (order > FLEX_ORDER_GORDER) return FLEX_ERR_INVALID;
     // graph orderings need the whole square matrix
@@ -201,6 +210,7 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
         std::iota(sched.begin(), sched.end(), static_cast<uint32_t>(r0));
     }
 
+    lap("row schedule");
     // chunk budget in records; rows longer than one budget are cut into pieces
     // chunk budget: short chunks keep the dispatcher's load balancing fine-grained on low-degree
     // graphs (flickr: best at ~96 records), long ones amortise the per-chunk descriptor chain on
@@ -297,6 +307,7 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     }
     if (m == 0) w_task.assign(1, 0u);
     if (rec.size() >= (size_t(1) << 32)) return FLEX_ERR_UNSUPPORTED;  // 32-bit record offsets
+    lap("records and tasks");
 
     p->n_tasks = static_cast<uint32_t>(t_dst.size());
     p->n_records = rec.size();
@@ -309,6 +320,7 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     if ((rc = upload(&p->d_rec, rec, &p->device_bytes))) return rc;
     if ((rc = upload(&p->d_t_beg, t_beg, &p->device_bytes))) return rc;
     if ((rc = upload(&p->d_t_dst, t_dst, &p->device_bytes))) return rc;
+    lap("upload records/tasks");
     // Chunk table in launch order: the kernel gives XCD x the x-th eighth of it.  The eighths are cut
     // by COST (records + per-row and per-chunk overhead), not by chunk count, and padded with empty
     // chunks to a common length: schedules that put the heavy rows at one end (degree order, RCM,
@@ -371,6 +383,7 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     p->partial_bytes = static_cast<uint32_t>(std::min<size_t>(pbytes, 0xFFFFFFFFu));
     FLEX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_partial), pbytes));
     p->device_bytes += static_cast<int64_t>(pbytes);
+    lap("chunk table, stats");
     return FLEX_OK;
 }
 
