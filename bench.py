@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
 """bench.py -- SpMM GFLOPS (2*nnz*k/t) of the MI355X-native engine, one process per GPU.
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload flickr] [--k 128]
+    python bench.py [--gpus N --steps K --warmup W] [--workload amazon] [--k 128]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one flex_spmm() over the whole (sharded) matrix with A's plan and B resident
-in HBM.  N=1 workload: BASELINE.json configs[1], the Flickr shape (89250^2, 989006 nnz),
-k=128, fp32 -- a synthetic stand-in with exactly that n and nnz (the reference ships only
-pubmed.csv).  N>1: weak scaling -- the same generator at N x n vertices and N x nnz
-nonzeros, reordered (community schedule), rows sharded over the ranks by flex_shard_rows, B broadcast once
-over RCCL (torch.distributed "nccl") before the timed region; no collective on the data path.
+in HBM.  Default workload, for every N: the configuration BASELINE.json's metric and target are quoted on --
+the Amazon shape (1 569 960^2, 264 339 468 nnz, values U(-1,1)), k=128, fp32 -- a synthetic stand-in with
+exactly that n and nnz (the reference ships only pubmed.csv); it fits one GPU (plan 2.3 GB + operands 1.6 GB).
+N>1: STRONG scaling of that same matrix (north_star: "rows of A partitioned across the 8 GPUs of one node with B
+broadcast once"): every rank derives the same community re-ordering, rows are sharded by flex_shard_rows, B is
+broadcast once over RCCL (torch.distributed "nccl") before the timed region; no collective on the data path.
+`--workload flickr|reddit|yelp|ppi|pubmed`, `--scaling weak` and `--graph file` remain as options.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and
 `cpu_baseline` objects.  The oracle is used here only for the reported CPU baseline.
@@ -31,14 +33,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="flickr", help="synthetic preset: flickr|reddit|amazon|yelp|ppi|pubmed")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="amazon", help="synthetic preset: flickr|reddit|amazon|yelp|ppi|pubmed")
     ap.add_argument("--graph", default=None, help="a real graph instead of a preset: .csv (the reference's format), .mtx or .bin "
                                                   "(e.g. tests/golden/pubmed.csv, the one data file the reference ships); strong scaling only")
     ap.add_argument("--k", type=int, default=128)
     ap.add_argument("--order", default="cluster", choices=["cluster", "rcm", "natural"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--shuffle", type=int, default=1, help="0: keep the generator's planted order (locality upper bound)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + FLEX_BENCH_DEVICE=0 rehearses the N>1 path on a one-GPU box (not a measurement)")
@@ -71,10 +73,19 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+                probe = torch.ones(1, device=torch.device("cuda", local_rank))
+                dist.all_reduce(probe)  # the communicator is created lazily: force RCCL up before any planning work
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"all_reduce over {world} ranks returned {probe.item()}")
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+        except Exception as e:  # noqa: BLE001 -- a rank that cannot reach the others must fail the job, not hang it
+            print(f"bench.py: rank {rank}: {args.backend} initialisation failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            os._exit(3)  # no destructor may block on a half-made communicator; the launcher tears the other ranks down
 
     k = args.k
     scale = world if args.scaling == "weak" else 1
@@ -153,10 +164,15 @@ def main():
     if world > 1:
         dist.barrier()
     dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream (torch's current stream)
+    per_rank = None
     if world > 1:
-        t = torch.tensor([wall, dev_ms], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall, dev_ms = float(t[0]), float(t[1])
+        # every rank's own figures (rank 0 reports them: which shard was the slow one), then the MAX over ranks
+        mine = torch.tensor([wall, dev_ms, float(shard_nnz), float(shard_rows)], device=dev if args.backend == "nccl" else "cpu",
+                            dtype=torch.float64)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [[float(x) for x in t_.tolist()] for t_ in allr]
+        wall, dev_ms = max(r[0] for r in per_rank), max(r[1] for r in per_rank)
 
     ok = None
     if args.check and rank == 0:
@@ -194,12 +210,22 @@ def main():
                 "plan": {"chunks": info["n_chunks"], "tasks": info["n_tasks"], "split_rows": info["n_split_rows"],
                          "lanes_per_nz": info["lanes_per_nz"], "plan_s": round(t_plan, 3), "gen_s": round(t_gen, 3)},
                 "b_bcast_ms": round(bcast_ms, 3),
+                # ≙ the README's "tPre/tElap" column (README.md:34-42): preprocessing (ordering + planning + upload) over
+                # one execution of the kernel
+                "tpre_over_telap": round(t_plan * 1e3 / max(kern_ms, 1e-9), 1),
             },
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(args, world),
                          "kernel": "spmm_flat_kernel", "kernel_ms": round(kern_ms, 6),
                          "algorithmic_bytes_per_launch": int(b_alg)},
         }
+        if per_rank is not None:
+            nnzs = [r[2] for r in per_rank]
+            out["config"]["per_rank_ms"] = [round(r[1] / args.steps, 6) for r in per_rank]        # HIP events, per step
+            out["config"]["per_rank_wall_ms"] = [round(r[0] * 1e3 / args.steps, 6) for r in per_rank]
+            out["config"]["per_rank_nnz"] = [int(x) for x in nnzs]
+            out["config"]["per_rank_rows"] = [int(r[3]) for r in per_rank]
+            out["config"]["shard_nnz_imbalance_pct"] = round(100.0 * max(nnzs) * world / max(sum(nnzs), 1.0) - 100.0, 2)
         if world == 1 and want_stats:  # ≙ B-Re1 / B-Re2 and alpha_stats_collect (flex.cu:5217-5223, mat.cu:944-1065)
             st = plan.stats()
             out["config"]["plan"].update({
@@ -237,12 +263,28 @@ def main():
         dist.destroy_process_group()
 
 
+TRAFFIC_SOURCES = ("spmm_kernels.hip", "plan.cpp", "internal.h", "cluster.cpp", "synth.cpp")
+
+
+def traffic_source_hash():
+    """Fingerprint of the sources that decide how many bytes a launch moves (kernel, planner, ordering, generator)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in TRAFFIC_SOURCES:
+        h.update(open(os.path.join(ROOT, "flex_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _pmc_traffic(args, world):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*.json), or null."""
+    """HBM-side bytes per launch (2*FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md's gfx950 correction) from the committed
+    rocprofv3 --pmc passes (profiles/pmc_traffic.json, written by tools/pmc.sh), or null: PMC counters cannot be read
+    inside the timed run, so the figure is only reported while the sources it was profiled at are the ones running."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        d = json.load(open(p))
-        return d.get(f"{args.workload}_k{args.k}_{args.order}_n{world}")
+        e = json.load(open(p)).get(f"{args.workload}_k{args.k}_{args.order}_n{world}")
+        if not isinstance(e, dict) or e.get("source_hash") != traffic_source_hash():
+            return None
+        return int(e["bytes"])
     except Exception:
         return None
 
@@ -301,8 +343,11 @@ def cpu_baseline(a, k, B):
     """The reference's CPU SpMM arithmetic (oracle port of aspt/sspmm_128.cu:1415-1422) timed on this
     host on a bounded sample of the same workload: the first rows holding <= ~3e9 flops."""
     import oracle
-    cores = min(os.cpu_count() or 1, 16)
-    budget = 3.0e9 / (2.0 * k)  # nonzeros
+    host_cores = os.cpu_count() or 1
+    # threads actually used by the multi-threaded leg: the share of the host one GPU's job is entitled to on the pool
+    # (16 of the box's cores), never more than the process may run on
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cores, 16)
+    budget = 1.0e10 / (2.0 * k)  # nonzeros: ~20 core-seconds of the scalar loop in all (3 threaded runs + 1 single-thread run)
     rp = a.rowPtr.astype(np.int64)
     rows = int(np.searchsorted(rp, budget, side="right")) - 1 if a.nnz > budget else a.m
     rows = max(rows, 1)
@@ -317,7 +362,7 @@ def cpu_baseline(a, k, B):
     t0 = time.perf_counter()
     oracle.spmm(rp_s, a.col[:nnz], a.vals[:nnz], Bh, nthreads=1)
     best1 = time.perf_counter() - t0
-    return {"value": round(2.0 * nnz * k / bestN / 1e9, 3), "unit": "GFLOPS", "cores": cores, "kind": "port",
+    return {"value": round(2.0 * nnz * k / bestN / 1e9, 3), "unit": "GFLOPS", "cores": cores, "host_cores": host_cores, "kind": "port",
             "sample": f"first {rows} rows ({nnz} nnz) of the same graph and B, best of 3",
             "single_thread_value": round(2.0 * nnz * k / best1 / 1e9, 3)}
 

@@ -13,6 +13,7 @@ from .binding import (  # noqa: F401
     FLEX_ORDER_GORDER,
     FLEX_PLAN_STATS,
     FLEX_PLAN_AUTOTUNE,
+    FLEX_PLAN_ROW_RANGE,
     FlexError,
     HostCsr,
     Plan,

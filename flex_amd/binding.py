@@ -23,6 +23,7 @@ FLEX_ORDER_CLUSTER = 2
 FLEX_ORDER_GORDER = 3
 FLEX_PLAN_STATS = 0x100
 FLEX_PLAN_AUTOTUNE = 0x200
+FLEX_PLAN_ROW_RANGE = 0x1000
 
 
 class FlexError(RuntimeError):
@@ -49,7 +50,7 @@ class _PlanInfo(C.Structure):  # flex_plan_info
                 ("nnz", C.c_int64), ("n_tasks", C.c_int64), ("n_chunks", C.c_int64),
                 ("n_split_rows", C.c_int64), ("n_partials", C.c_int64),
                 ("device_bytes", C.c_int64), ("lanes_per_nz", C.c_int32), ("order", C.c_int32),
-                ("plan_ms", C.c_double), ("n_slots", C.c_int64)]
+                ("plan_ms", C.c_double), ("n_slots", C.c_int64), ("two_d", C.c_int32), ("panel_rows", C.c_int32)]
 
 
 class _PlanStats(C.Structure):  # flex_plan_stats
@@ -352,7 +353,8 @@ class Plan:
             cm = None if col_map is None else np.ascontiguousarray(col_map, dtype=np.int32)
             vm = None if vo_mp is None else np.ascontiguousarray(vo_mp, dtype=np.int32)
             self._keep = (a, cm, vm)
-            d = _PlanDesc(C.sizeof(_PlanDesc), C.pointer(v), k, ldb or 0, ldc or 0, device, order,
+            d = _PlanDesc(C.sizeof(_PlanDesc), C.pointer(v), k, ldb or 0, ldc or 0, device,
+                          order | (0 if rows is None else FLEX_PLAN_ROW_RANGE),
                           0 if rows is None else int(rows[0]), 0 if rows is None else int(rows[1]),
                           (cm if cm is not None else vm).ctypes.data if (cm is not None or vm is not None) else None,
                           None if vm is None else vm.ctypes.data)

@@ -60,6 +60,9 @@ bool parse_u32(const char *b, const char *e, uint32_t &out) {  // std::stoi sema
     long long v = 0;
     auto r = std::from_chars(b, e, v);
     if (r.ec != std::errc() || r.ptr == b) return false;
+    // std::stoi throws std::out_of_range past INT_MAX and the reference stores the result in an unsigned (DataLoader.cu:21-33):
+    // a negative or >32-bit token must fail here, not wrap into a valid-looking index
+    if (v < 0 || v > static_cast<long long>(UINT32_MAX)) return false;
     out = static_cast<uint32_t>(v);
     return true;
 }

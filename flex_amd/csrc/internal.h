@@ -18,13 +18,12 @@ struct SplitRow {
 struct PlanView {
     const uint2 *rec;        // [nnz] {x = B-row byte offset (off32) or column id, y = value bits}, task order
     const uint32_t *t_beg;   // [n_tasks+1] first record of each task
-    const uint32_t *t_dst;   // [n_tasks]   C row written by the task; MSB set -> partial slot id
+    const uint32_t *t_dst;   // [n_tasks]   C row written by the task; MSB set -> partial slot id (the task is a PIECE)
+    const uint2 *t_aux;      // [n_tasks]   pieces: {index into `split` of the piece's row, #pieces of that row}; else {0,0}
     const uint4 *chunk;      // [n_chunks] {first task, #tasks (<= 63), first record, end record}; one wave per chunk
     float *partial;          // [n_partials][k] partial sums of split rows
-    const uint32_t *piece_row;  // [n_partials] index into `split` of the row a piece belongs to
     const SplitRow *split;   // [n_split] {C row, first partial, #pieces}
     uint32_t *split_cnt;     // [n_split][k-tiles] arrival counters, zero between launches
-    uint32_t partial_bytes;  // size of `partial` (buffer-descriptor range)
     uint32_t fused_fixup;    // 1: the last piece to finish sums the row inside the launch; 0: spmm_fixup_kernel does
     uint32_t n_chunks;
     int32_t k;

@@ -12,6 +12,7 @@
 // the ORIGINAL B, rows always write the ORIGINAL C row, so no permuteX pass and
 // no shadow copy of B exist (flex.cu:276-289, mat.cu:287-290).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -20,6 +21,7 @@
 #include <new>
 #include <numeric>
 
+#include "host_parallel.h"
 #include "internal.h"
 
 namespace flex {
@@ -65,12 +67,14 @@ struct flex_plan {
     unsigned order = 0;
     uint2 *d_rec = nullptr;
     uint32_t *d_t_beg = nullptr, *d_t_dst = nullptr;
+    uint2 *d_t_aux = nullptr;
     uint4 *d_chunk = nullptr;
     float *d_partial = nullptr;
     SplitRow *d_split = nullptr;
-    uint32_t *d_piece_row = nullptr, *d_split_cnt = nullptr;
-    uint32_t partial_bytes = 0;
+    uint32_t *d_split_cnt = nullptr;
     bool fused_fixup = false;
+    bool two_d = false;  // rows cut by column panel (phases), not only by length
+    uint32_t panel_rows = 0;
     uint32_t n_tasks = 0, n_chunks = 0, n_slots = 0, n_split = 0, n_partials = 0;  // n_slots: chunk table incl. padding
     uint64_t n_records = 0;   // nnz + padding
     int64_t c_rows = 0;       // rows of C the plan writes into (m, or hostA->m for a mapped plan)
@@ -96,10 +100,10 @@ void free_plan_device(flex_plan *p) {
     (void)hipFree(p->d_rec);
     (void)hipFree(p->d_t_beg);
     (void)hipFree(p->d_t_dst);
+    (void)hipFree(p->d_t_aux);
     (void)hipFree(p->d_chunk);
     (void)hipFree(p->d_partial);
     (void)hipFree(p->d_split);
-    (void)hipFree(p->d_piece_row);
     (void)hipFree(p->d_split_cnt);
 }
 
@@ -227,39 +231,6 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     p->xcd_remap = env_long("FLEX_XCD_REMAP", 1) != 2;  // 2 = off (tuning experiments only)
     p->lds_extra = static_cast<unsigned>(env_long("FLEX_LDS_EXTRA", 1)) & ~15u;  // default 0 (1 -> 0)
     const uint32_t S = 64u / static_cast<uint32_t>(G);      // records per step: rows are padded to it
-
-    std::vector<uint32_t> t_beg, t_dst, w_task;
-    std::vector<SplitRow> split;
-    std::vector<uint2> rec;
-    try {
-        t_beg.reserve(static_cast<size_t>(m) + 1);
-        t_dst.reserve(m);
-        rec.reserve(static_cast<size_t>(A->rowPtr[r1] - A->rowPtr[r0]) + static_cast<size_t>(m) * (S - 1) / 2 + 64);
-    } catch (const std::bad_alloc &) {
-        return FLEX_ERR_NOMEM;
-    }
-    uint32_t n_partials = 0;
-    uint32_t wave_cost = 0;
-    int64_t split_nnz = 0;
-    const uint32_t row_bytes32 = static_cast<uint32_t>(p->ldb) * 4u;
-    auto emit_records = [&](uint32_t e0, uint32_t e1) {
-        for (uint32_t e = e0; e < e1; ++e) {
-            uint32_t c = A->col[e];
-            if (col_map) c = static_cast<uint32_t>(col_map[c]);
-            uint32_t bits;
-            std::memcpy(&bits, &A->vals[e], 4);
-            rec.push_back(make_uint2(p->off32 ? c * row_bytes32 : c, bits));
-        }
-        // pad to a whole number of steps: value 0, B row = the last real one (always a valid address)
-        while (e1 > e0 && rec.size() % S != 0) rec.push_back(make_uint2(rec.back().x, 0u));
-    };
-    constexpr uint32_t kMaxTasksPerWave = 63;  // kernel hands descriptors out by lane (process_chunk)
-    auto open_wave_if_needed = [&]() {
-        if (w_task.empty() || wave_cost >= wave_nnz || t_dst.size() - w_task.back() >= kMaxTasksPerWave) {
-            w_task.push_back(static_cast<uint32_t>(t_dst.size()));
-            wave_cost = 0;
-        }
-    };
     // Rows longer than one budget are cut into pieces of one budget, each a chunk of its own that
     // writes a k-wide partial sum: one wave keeps only U gathers in flight, so a long row is much
     // faster as several concurrent pieces (flickr, MI355X: 88 us with no splitting, 43 us with
@@ -267,87 +238,345 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     // DESIGN.md 3.3).  Pieces stay in schedule order: moving them to the
     // front of the XCD slices helped flickr by 3 % and cost reddit 12 % (half its chunks are pieces).
     const uint32_t long_row = static_cast<uint32_t>(env_long("FLEX_LONG_ROW", wave_nnz));
-    const uint32_t piece = std::max<uint32_t>(S, static_cast<uint32_t>(env_long("FLEX_PIECE", wave_nnz)) / S * S);
-    try {
-        for (int32_t i = 0; i < m; ++i) {
-            const uint32_t r = sched[i];
-            const uint32_t e0 = A->rowPtr[r], e1 = A->rowPtr[r + 1];
-            const uint32_t len = e1 - e0;
-            const uint32_t dst = dst_map ? static_cast<uint32_t>(dst_map[r]) : r - static_cast<uint32_t>(r0);
-            if (len > long_row) {
-                // The last piece to arrive sums all of them with ONE wave, so a hub of 10^6 nonzeros cut into 10^4
-                // budget-sized pieces spent 0.9 ms in that sum alone (tools/probe_hub.py: 1263 us against 358 us
-                // without the hub).  At most 256 pieces per row, longer ones instead: 564 us (774 pieces: 601 us).
-                constexpr uint32_t kMaxPieces = 256;
-                const uint32_t nchunk = std::min<uint32_t>((len + piece - 1) / piece, kMaxPieces);
-                const uint32_t per = ((len + nchunk - 1) / nchunk + S - 1) / S * S;  // whole steps
-                split.push_back({dst, n_partials, 0});
-                split_nnz += len;
-                for (uint32_t c0 = e0; c0 < e1; c0 += per) {
-                    const uint32_t c1 = std::min(e1, c0 + per);
-                    w_task.push_back(static_cast<uint32_t>(t_dst.size()));  // a piece is a chunk of its own
-                    t_beg.push_back(static_cast<uint32_t>(rec.size()));
-                    t_dst.push_back(kPartialFlag | n_partials++);
-                    emit_records(c0, c1);
-                    split.back().count++;
-                }
-                wave_cost = wave_nnz;  // the next ordinary row opens a fresh chunk
-            } else {
-                open_wave_if_needed();
-                t_beg.push_back(static_cast<uint32_t>(rec.size()));
-                t_dst.push_back(dst);
-                emit_records(e0, e1);
-                wave_cost += len + row_cost;
-            }
+    const uint32_t piece_len = std::max<uint32_t>(S, static_cast<uint32_t>(env_long("FLEX_PIECE", wave_nnz)) / S * S);
+
+    // ---- column panels (the 2-D schedule; ≙ the column spans of csr2_DiagTiling's rounds 2-3, mat.cu:680-942, and
+    // csr2seg_Cmajor, mat.cu:1192-1269, re-thought for eight private 4 MiB L2s).  An XCD walks ONE contiguous slice of
+    // the rows; in 1-D that slice is walked row by row and the B rows it needs within +-w communities (megabytes)
+    // are evicted between uses.  In 2-D the slice is walked PHASE by PHASE: phase q holds, for every row of the
+    // slice, the records whose column lies in panel q of B (P rows = `panel_bytes` of one column tile, about half an
+    // L2), so whatever the resident waves gather at one time comes from one or two panels and hits the L2 by
+    // construction; the price is that a row with records in several phases is summed from several pieces (a k-wide
+    // partial sum written and read once per piece).  Only runs of >= `seg_min` records of a row in one panel become a
+    // piece; the rest of the row (its scattered columns, which miss either way) is ONE more piece in a last phase.
+    const int64_t slice_nnz = static_cast<int64_t>(A->rowPtr[r1]) - A->rowPtr[r0];
+    const uint64_t tile_bytes = 16ull * static_cast<uint64_t>(G);  // one B row of one column tile
+    const long mode_2d = env_long("FLEX_2D", 0);                    // 1 = on, 2 = off, otherwise the rule below
+    bool two_d = mode_2d == 1 && m > 0;  // forced (tests, tuning): any size
+    if (mode_2d != 1 && mode_2d != 2) two_d = false;  // rule: decided by measurement
+    const uint64_t panel_bytes = static_cast<uint64_t>(env_long("FLEX_PANEL_KB", 2048)) << 10;
+    uint32_t pshift = 0;
+    while ((2ull << pshift) * tile_bytes <= panel_bytes) ++pshift;  // P = 2^pshift rows of B per panel
+    const uint32_t seg_min = static_cast<uint32_t>(env_long("FLEX_SEG_MIN", 4));
+    constexpr uint32_t kFarPhase = 0xFFFFFFFEu;
+
+    // position of a column's vertex in the schedule (what "near" means for a reordered square matrix); for a
+    // natural-order plan, a mapped plan or a row shard the column ids of A are positions already
+    std::vector<uint32_t> colpos;
+    if (two_d && order != FLEX_ORDER_NATURAL) {
+        colpos.resize(static_cast<size_t>(m));
+        for (int32_t i = 0; i < m; ++i) colpos[sched[i]] = static_cast<uint32_t>(i);
+    }
+
+    struct Piece {
+        uint32_t spos;       // position of the piece's row in the schedule
+        uint32_t beg, end;   // its records [beg,end) in rcol/rval
+        uint32_t phase;      // 0 in 1-D; column panel + 1, or kFarPhase, in 2-D
+        uint32_t own_chunk;  // a slice of a run longer than one budget: a chunk of its own
+    };
+    std::vector<Piece> pieces;
+    std::vector<uint32_t> row_first_piece(static_cast<size_t>(m) + 1, 0u);
+    std::vector<uint32_t> pcol;  // 2-D: the records of every row re-grouped by piece (index e - e_base)
+    std::vector<float> pval;
+    const uint32_t e_base = A->rowPtr[r0];
+    const uint32_t *rcol = A->col;
+    const float *rval = A->vals;
+    uint32_t r_off = 0;  // rcol[e - r_off]
+    // a run of `len` records as pieces: one, or (longer than a budget) several of about one budget.  The last piece to
+    // arrive sums all of them with ONE wave, so a hub of 10^6 nonzeros cut into 10^4 budget-sized pieces spent 0.9 ms
+    // in that sum alone (tools/probe_hub.py: 1263 us against 358 us without the hub): at most 256 pieces per run,
+    // longer ones instead: 564 us (774 pieces: 601 us).
+    auto cut_run = [&](std::vector<Piece> &out, uint32_t spos, uint32_t b, uint32_t e, uint32_t phase) {
+        const uint32_t len = e - b;
+        if (len <= long_row) {
+            out.push_back({spos, b, e, phase, 0u});
+            return;
         }
-        t_beg.push_back(static_cast<uint32_t>(rec.size()));
-        w_task.push_back(static_cast<uint32_t>(t_dst.size()));
+        constexpr uint32_t kMaxPieces = 256;
+        const uint32_t nchunk = std::min<uint32_t>((len + piece_len - 1) / piece_len, kMaxPieces);
+        const uint32_t per = ((len + nchunk - 1) / nchunk + S - 1) / S * S;  // whole steps
+        for (uint32_t c0 = b; c0 < e; c0 += per) out.push_back({spos, c0, std::min(e, c0 + per), phase, 1u});
+    };
+    try {
+        if (!two_d) {
+            pieces.reserve(static_cast<size_t>(m) + 1024);
+            for (int32_t i = 0; i < m; ++i) {
+                const uint32_t r = sched[i];
+                row_first_piece[i] = static_cast<uint32_t>(pieces.size());
+                cut_run(pieces, static_cast<uint32_t>(i), A->rowPtr[r], A->rowPtr[r + 1], 0u);
+            }
+            row_first_piece[m] = static_cast<uint32_t>(pieces.size());
+        } else {
+            pcol.resize(static_cast<size_t>(slice_nnz));
+            pval.resize(static_cast<size_t>(slice_nnz));
+            constexpr int64_t kBlk = 1024;  // schedule positions per work item
+            const int64_t nblk = (m + kBlk - 1) / kBlk;
+            std::vector<std::vector<Piece>> blk(static_cast<size_t>(nblk));
+            std::vector<uint32_t> row_np(static_cast<size_t>(m), 0u);
+            std::atomic<int> failed{0};
+            parallel_chunks(nblk, [&](int64_t b) {
+                try {
+                    std::vector<Piece> &out = blk[static_cast<size_t>(b)];
+                    std::vector<uint64_t> key;  // (panel << 32) | index within the row
+                    std::vector<uint32_t> run_beg, run_pan;
+                    for (int64_t i = b * kBlk; i < std::min<int64_t>(m, (b + 1) * kBlk); ++i) {
+                        const uint32_t r = sched[i];
+                        const uint32_t e0 = A->rowPtr[r], e1 = A->rowPtr[r + 1], len = e1 - e0;
+                        const size_t before = out.size();
+                        const uint32_t o0 = e0 - e_base;
+                        if (len == 0) {
+                            out.push_back({static_cast<uint32_t>(i), o0, o0, kFarPhase, 0u});
+                            row_np[i] = 1;
+                            continue;
+                        }
+                        key.resize(len);
+                        bool sorted = true;
+                        for (uint32_t z = 0; z < len; ++z) {
+                            const uint32_t c = A->col[e0 + z];
+                            const uint32_t pan = (colpos.empty() ? c : colpos[c]) >> pshift;
+                            key[z] = (static_cast<uint64_t>(pan) << 32) | z;
+                            sorted = sorted && (z == 0 || key[z - 1] <= key[z]);
+                        }
+                        if (!sorted) std::sort(key.begin(), key.end());  // by panel, original order within a panel
+                        run_beg.clear();
+                        run_pan.clear();
+                        for (uint32_t z = 0; z < len; ++z)
+                            if (z == 0 || (key[z] >> 32) != (key[z - 1] >> 32)) {
+                                run_beg.push_back(z);
+                                run_pan.push_back(static_cast<uint32_t>(key[z] >> 32));
+                            }
+                        run_beg.push_back(len);
+                        // layout of the row in pcol/pval: the kept runs in panel order, then everything else
+                        uint32_t o = o0, n_far = 0, n_kept = 0;
+                        for (size_t q = 0; q + 1 < run_beg.size(); ++q) {
+                            const uint32_t cnt = run_beg[q + 1] - run_beg[q];
+                            if (cnt < seg_min) {
+                                n_far += cnt;
+                                continue;
+                            }
+                            for (uint32_t z = run_beg[q]; z < run_beg[q + 1]; ++z) {
+                                const uint32_t e = e0 + static_cast<uint32_t>(key[z] & 0xFFFFFFFFu);
+                                pcol[o] = A->col[e];
+                                pval[o] = A->vals[e];
+                                ++o;
+                            }
+                            ++n_kept;
+                            cut_run(out, static_cast<uint32_t>(i), o - cnt, o, run_pan[q] + 1);
+                        }
+                        const uint32_t far_beg = o;
+                        if (n_far)
+                            for (size_t q = 0; q + 1 < run_beg.size(); ++q) {
+                                if (run_beg[q + 1] - run_beg[q] >= seg_min) continue;
+                                for (uint32_t z = run_beg[q]; z < run_beg[q + 1]; ++z) {
+                                    const uint32_t e = e0 + static_cast<uint32_t>(key[z] & 0xFFFFFFFFu);
+                                    pcol[o] = A->col[e];
+                                    pval[o] = A->vals[e];
+                                    ++o;
+                                }
+                            }
+                        if (n_far) {
+                            // a remainder too short to pay for a piece of its own rides with the row's last kept run
+                            if (n_far < seg_min && n_kept > 0 && out.back().own_chunk == 0) out.back().end = o;
+                            else cut_run(out, static_cast<uint32_t>(i), far_beg, o, kFarPhase);
+                        }
+                        row_np[i] = static_cast<uint32_t>(out.size() - before);
+                    }
+                } catch (...) {
+                    failed.store(1);
+                }
+            });
+            if (failed.load()) return FLEX_ERR_NOMEM;
+            size_t total = 0;
+            for (int32_t i = 0; i < m; ++i) {
+                row_first_piece[i] = static_cast<uint32_t>(total);
+                total += row_np[i];
+            }
+            row_first_piece[m] = static_cast<uint32_t>(total);
+            if (total >= (size_t(1) << 31)) return FLEX_ERR_UNSUPPORTED;
+            pieces.resize(total);
+            parallel_chunks(nblk, [&](int64_t b) {
+                const std::vector<Piece> &src = blk[static_cast<size_t>(b)];
+                if (!src.empty()) std::copy(src.begin(), src.end(), pieces.begin() + row_first_piece[b * kBlk]);
+            });
+            rcol = pcol.data();
+            rval = pval.data();
+            r_off = 0;  // piece ranges are already relative to e_base
+        }
     } catch (const std::bad_alloc &) {
         return FLEX_ERR_NOMEM;
     }
-    if (m == 0) w_task.assign(1, 0u);
-    if (rec.size() >= (size_t(1) << 32)) return FLEX_ERR_UNSUPPORTED;  // 32-bit record offsets
+    const size_t n_pieces = pieces.size();
+    lap("pieces");
+
+    // ---- XCD slices of the rows (2-D: cut here, by records + row overhead; 1-D: the chunk table is cut by cost below)
+    uint32_t slice_row[kXcds + 1] = {0};
+    slice_row[kXcds] = static_cast<uint32_t>(m);
+    if (two_d) {
+        std::vector<uint64_t> cum(static_cast<size_t>(m) + 1, 0);
+        for (int32_t i = 0; i < m; ++i) {
+            const uint32_t r = sched[i];
+            cum[i + 1] = cum[i] + (A->rowPtr[r + 1] - A->rowPtr[r]) + row_cost;
+        }
+        for (int x = 1; x < kXcds; ++x)
+            slice_row[x] = std::max<uint32_t>(slice_row[x - 1], static_cast<uint32_t>(std::lower_bound(cum.begin(), cum.end(), cum[m] * x / kXcds) - cum.begin()));
+    }
+
+    // ---- emission order: 1-D = schedule order; 2-D = per slice, phase by phase (rows in schedule order inside a phase)
+    std::vector<uint32_t> emit(n_pieces);
+    std::iota(emit.begin(), emit.end(), 0u);
+    if (two_d) {
+        parallel_chunks(kXcds, [&](int64_t x) {
+            auto b = emit.begin() + row_first_piece[slice_row[x]], e = emit.begin() + row_first_piece[slice_row[x + 1]];
+            std::stable_sort(b, e, [&](uint32_t u, uint32_t v) { return pieces[u].phase < pieces[v].phase; });
+        });
+    }
+    lap("emission order");
+
+    // ---- rows summed from several pieces: partial slots (consecutive per row, in piece order) + arrival bookkeeping
+    std::vector<SplitRow> split;
+    std::vector<uint32_t> row_sidx(static_cast<size_t>(m), 0u), row_first_partial(static_cast<size_t>(m), 0u);
+    uint32_t n_partials = 0;
+    int64_t split_nnz = 0;
+    try {
+        for (int32_t i = 0; i < m; ++i) {
+            const uint32_t np = row_first_piece[i + 1] - row_first_piece[i];
+            if (np <= 1) continue;
+            const uint32_t r = sched[i];
+            const uint32_t dst = dst_map ? static_cast<uint32_t>(dst_map[r]) : r - static_cast<uint32_t>(r0);
+            row_sidx[i] = static_cast<uint32_t>(split.size());
+            row_first_partial[i] = n_partials;
+            split.push_back({dst, n_partials, np});
+            n_partials += np;
+            split_nnz += A->rowPtr[r + 1] - A->rowPtr[r];
+        }
+    } catch (const std::bad_alloc &) {
+        return FLEX_ERR_NOMEM;
+    }
+
+    // ---- tasks (one per piece, in emission order), their records, and the chunks (one wave each)
+    const uint32_t n_tasks = static_cast<uint32_t>(n_pieces);
+    std::vector<uint32_t> t_beg, t_dst, w_task;
+    std::vector<uint2> t_aux, rec;
+    uint32_t slice_chunk[kXcds + 1] = {0};
+    constexpr uint32_t kMaxTasksPerWave = 63;  // the kernel hands descriptors out by lane (compute_chunk)
+    try {
+        t_beg.resize(static_cast<size_t>(n_tasks) + 1);
+        t_dst.resize(n_tasks);
+        t_aux.resize(n_tasks);
+        uint64_t pos = 0;
+        uint32_t wave_cost = 0, cur_phase = 0, prev_own = 0;
+        int cur_slice = 0;
+        for (uint32_t t = 0; t < n_tasks; ++t) {
+            const Piece &pc = pieces[emit[t]];
+            const uint32_t len = pc.end - pc.beg;
+            bool fresh = w_task.empty() || wave_cost >= wave_nnz || t - w_task.back() >= kMaxTasksPerWave || pc.own_chunk || prev_own;
+            if (two_d) {
+                while (pc.spos >= slice_row[cur_slice + 1]) {  // first task of the next XCD slice
+                    slice_chunk[++cur_slice] = static_cast<uint32_t>(w_task.size());
+                    fresh = true;
+                }
+                if (pc.phase != cur_phase) fresh = true;  // a chunk never straddles two panels
+                cur_phase = pc.phase;
+            }
+            if (fresh) {
+                w_task.push_back(t);
+                wave_cost = 0;
+            }
+            wave_cost += len + row_cost;
+            prev_own = pc.own_chunk;
+            t_beg[t] = static_cast<uint32_t>(pos);
+            pos += (len + S - 1) / S * S;  // padded to a whole number of steps
+            if (pos >= (uint64_t(1) << 32)) return FLEX_ERR_UNSUPPORTED;  // 32-bit record offsets
+        }
+        t_beg[n_tasks] = static_cast<uint32_t>(pos);
+        w_task.push_back(n_tasks);
+        if (m == 0) w_task.assign(1, 0u);
+        if (two_d)
+            while (cur_slice < kXcds) slice_chunk[++cur_slice] = static_cast<uint32_t>(w_task.size() - 1);
+        rec.resize(static_cast<size_t>(pos));
+    } catch (const std::bad_alloc &) {
+        return FLEX_ERR_NOMEM;
+    }
+    const uint32_t row_bytes32 = static_cast<uint32_t>(p->ldb) * 4u;
+    {
+        constexpr int64_t kTaskBlk = 4096;
+        parallel_chunks((static_cast<int64_t>(n_tasks) + kTaskBlk - 1) / kTaskBlk, [&](int64_t b) {
+            for (int64_t t = b * kTaskBlk; t < std::min<int64_t>(n_tasks, (b + 1) * kTaskBlk); ++t) {
+                const uint32_t pi = emit[t];
+                const Piece &pc = pieces[pi];
+                const uint32_t i = pc.spos, r = sched[i];
+                const uint32_t np = row_first_piece[i + 1] - row_first_piece[i];
+                if (np > 1) {
+                    t_dst[t] = kPartialFlag | (row_first_partial[i] + (pi - row_first_piece[i]));
+                    t_aux[t] = make_uint2(row_sidx[i], np);
+                } else {
+                    t_dst[t] = dst_map ? static_cast<uint32_t>(dst_map[r]) : r - static_cast<uint32_t>(r0);
+                    t_aux[t] = make_uint2(0u, 0u);
+                }
+                uint2 *o = rec.data() + t_beg[t];
+                for (uint32_t e = pc.beg; e < pc.end; ++e) {
+                    uint32_t c = rcol[e - r_off];
+                    if (col_map) c = static_cast<uint32_t>(col_map[c]);
+                    uint32_t bits;
+                    std::memcpy(&bits, &rval[e - r_off], 4);
+                    *o++ = make_uint2(p->off32 ? c * row_bytes32 : c, bits);
+                }
+                // pad to a whole number of steps: value 0, B row = the last real one (always a valid address)
+                for (uint2 *end = rec.data() + t_beg[t + 1]; o < end; ++o) *o = make_uint2(o[-1].x, 0u);
+            }
+        });
+    }
+    pcol = std::vector<uint32_t>();
+    pval = std::vector<float>();
     lap("records and tasks");
 
-    p->n_tasks = static_cast<uint32_t>(t_dst.size());
+    p->n_tasks = n_tasks;
     p->n_records = rec.size();
     p->c_rows = dst_map ? A->m : m;
     p->n_chunks = static_cast<uint32_t>(w_task.size() - 1);
     p->n_split = static_cast<uint32_t>(split.size());
     p->n_partials = n_partials;
+    p->two_d = two_d;
+    p->panel_rows = 1u << pshift;
 
     int rc;
     if ((rc = upload(&p->d_rec, rec, &p->device_bytes))) return rc;
     if ((rc = upload(&p->d_t_beg, t_beg, &p->device_bytes))) return rc;
     if ((rc = upload(&p->d_t_dst, t_dst, &p->device_bytes))) return rc;
+    if ((rc = upload(&p->d_t_aux, t_aux, &p->device_bytes))) return rc;
     lap("upload records/tasks");
     // Chunk table in launch order: the kernel gives XCD x the x-th eighth of it.  The eighths are cut
     // by COST (records + per-row and per-chunk overhead), not by chunk count, and padded with empty
     // chunks to a common length: schedules that put the heavy rows at one end (degree order, RCM,
     // Gorder) otherwise leave one XCD with up to 1.9x the mean work (flickr shape).
+    // (2-D: the eighths are the row slices cut above -- a slice's phases must stay on one XCD.)
     const uint32_t n_real = static_cast<uint32_t>(w_task.size() - 1);
     auto header = [&](uint32_t c) {
         return make_uint4(w_task[c], w_task[c + 1] - w_task[c], t_beg[w_task[c]], t_beg[w_task[c + 1]]);
     };
     std::vector<uint4> chunk;
-    if (p->xcd_remap && n_real >= 8u * kXcds * kWavesPerBlock && env_long("FLEX_XCD_BALANCE", 1) != 2) {
-        // cost of a chunk in units of one 512-byte gather (a record at k = 128): measured per-XCD times
-        // on the flickr shape fit  t = a * records + ~20 a * chunks  with rows nearly free
-        const uint64_t chunk_cost = static_cast<uint64_t>(env_long("FLEX_CHUNK_COST", 16)) * 32u;
-        const uint64_t task_cost = static_cast<uint64_t>(env_long("FLEX_TASK_COST", 2)) * 32u;
-        std::vector<uint64_t> cum(n_real + 1, 0);
-        for (uint32_t c = 0; c < n_real; ++c) {
-            const uint4 h = header(c);
-            cum[c + 1] = cum[c] + static_cast<uint64_t>(h.w - h.z) * static_cast<uint32_t>(G) + task_cost * h.y + chunk_cost;
-        }
+    if (two_d || (p->xcd_remap && n_real >= 8u * kXcds * kWavesPerBlock && env_long("FLEX_XCD_BALANCE", 1) != 2)) {
         uint32_t cut[kXcds + 1];
         cut[0] = 0;
         cut[kXcds] = n_real;
-        for (uint32_t x = 1; x < kXcds; ++x) {
-            const uint64_t want = cum[n_real] * x / kXcds;
-            uint32_t c = static_cast<uint32_t>(std::lower_bound(cum.begin(), cum.end(), want) - cum.begin());
-            c = (c + kWavesPerBlock / 2) / kWavesPerBlock * kWavesPerBlock;  // whole workgroups
-            cut[x] = std::clamp(c, cut[x - 1], n_real);
+        if (two_d) {
+            for (uint32_t x = 1; x < kXcds; ++x) cut[x] = slice_chunk[x];
+        } else {
+            // cost of a chunk in units of one 512-byte gather (a record at k = 128): measured per-XCD times
+            // on the flickr shape fit  t = a * records + ~20 a * chunks  with rows nearly free
+            const uint64_t chunk_cost = static_cast<uint64_t>(env_long("FLEX_CHUNK_COST", 16)) * 32u;
+            const uint64_t task_cost = static_cast<uint64_t>(env_long("FLEX_TASK_COST", 2)) * 32u;
+            std::vector<uint64_t> cum(n_real + 1, 0);
+            for (uint32_t c = 0; c < n_real; ++c) {
+                const uint4 h = header(c);
+                cum[c + 1] = cum[c] + static_cast<uint64_t>(h.w - h.z) * static_cast<uint32_t>(G) + task_cost * h.y + chunk_cost;
+            }
+            for (uint32_t x = 1; x < kXcds; ++x) {
+                const uint64_t want = cum[n_real] * x / kXcds;
+                uint32_t c = static_cast<uint32_t>(std::lower_bound(cum.begin(), cum.end(), want) - cum.begin());
+                c = (c + kWavesPerBlock / 2) / kWavesPerBlock * kWavesPerBlock;  // whole workgroups
+                cut[x] = std::clamp(c, cut[x - 1], n_real);
+            }
         }
         uint32_t longest = 0;
         for (uint32_t x = 0; x < kXcds; ++x) longest = std::max(longest, cut[x + 1] - cut[x]);
@@ -370,17 +599,11 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
         }
     }
     if ((rc = upload(&p->d_split, split, &p->device_bytes))) return rc;
-    std::vector<uint32_t> piece_row(n_partials);
-    for (uint32_t si = 0; si < split.size(); ++si)
-        for (uint32_t j = 0; j < split[si].count; ++j) piece_row[split[si].first + j] = si;
-    if ((rc = upload(&p->d_piece_row, piece_row, &p->device_bytes))) return rc;
     const size_t ktiles = (static_cast<size_t>(k) + 4 * G - 1) / (4 * G);
     std::vector<uint32_t> zeros(std::max<size_t>(1, split.size() * ktiles), 0u);
     if ((rc = upload(&p->d_split_cnt, zeros, &p->device_bytes))) return rc;
     const size_t pbytes = std::max<size_t>(1, static_cast<size_t>(n_partials) * k) * sizeof(float);
-    // the in-launch reduction addresses `partial` through a buffer descriptor (32-bit range)
-    p->fused_fixup = pbytes < (size_t(1) << 32) && env_long("FLEX_FUSED_FIXUP", 1) == 1;
-    p->partial_bytes = static_cast<uint32_t>(std::min<size_t>(pbytes, 0xFFFFFFFFu));
+    p->fused_fixup = env_long("FLEX_FUSED_FIXUP", 1) == 1;
     FLEX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_partial), pbytes));
     p->device_bytes += static_cast<int64_t>(pbytes);
     lap("chunk table, stats");
@@ -542,11 +765,11 @@ int flex_plan_create_rows(flex_plan **out, const flex_csr *hostA, int64_t row_be
 
 int flex_plan_create_ex(flex_plan **out, const flex_plan_desc *d) {
     if (!d || !d->A || d->struct_size != sizeof(flex_plan_desc)) return FLEX_ERR_INVALID;
-    const bool all_rows = d->row_begin == 0 && d->row_end == 0;
+    const bool all_rows = (d->flags & FLEX_PLAN_ROW_RANGE) == 0;  // with the flag, (0,0) is an EMPTY shard, not "everything"
     const int64_t r0 = d->row_begin, r1 = all_rows ? d->A->m : d->row_end;
     if (d->row_map && (!all_rows || d->A->m != d->A->n)) return FLEX_ERR_INVALID;  // a row map renames ALL rows of a graph
     if (!all_rows && (d->flags & FLEX_ORDER_MASK) != FLEX_ORDER_NATURAL) return FLEX_ERR_INVALID;  // reorder first, then shard
-    return create_common(out, d->A, r0, r1, d->col_map, d->row_map, d->k, d->device, d->flags, d->ldb, d->ldc);
+    return create_common(out, d->A, all_rows ? 0 : r0, r1, d->col_map, d->row_map, d->k, d->device, d->flags & ~FLEX_PLAN_ROW_RANGE, d->ldb, d->ldc);
 }
 
 int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream) {
@@ -559,8 +782,8 @@ int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream) {
     const bool vec4 = (p->k % 4 == 0) && (p->ldb % 4 == 0) && (p->ldc % 4 == 0) &&
                       ((reinterpret_cast<uintptr_t>(dB) | reinterpret_cast<uintptr_t>(dC)) % 16 == 0);
     const bool fused = vec4 && p->fused_fixup;  // the generic kernel always leaves the sum to spmm_fixup_kernel
-    PlanView v{p->d_rec, p->d_t_beg, p->d_t_dst, p->d_chunk, p->d_partial, p->d_piece_row, p->d_split, p->d_split_cnt,
-               p->partial_bytes, fused ? 1u : 0u, p->n_slots, p->k, p->ldb, p->ldc,
+    PlanView v{p->d_rec, p->d_t_beg, p->d_t_dst, p->d_t_aux, p->d_chunk, p->d_partial, p->d_split, p->d_split_cnt,
+               fused ? 1u : 0u, p->n_slots, p->k, p->ldb, p->ldc,
                p->xcd_remap ? 1u : 0u, p->lds_extra, p->trace};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc = launch_spmm(v, p->lanes_per_nz, p->off32, vec4, dB, dC, s);
@@ -596,6 +819,8 @@ int flex_plan_get_info(const flex_plan *p, flex_plan_info *o) {
     o->order = static_cast<int32_t>(p->order);
     o->plan_ms = p->plan_ms;
     o->n_slots = p->n_slots;
+    o->two_d = p->two_d ? 1 : 0;
+    o->panel_rows = p->two_d ? static_cast<int32_t>(p->panel_rows) : 0;
     return FLEX_OK;
 }
 
@@ -632,14 +857,14 @@ int flex_plan_self_check(const flex_plan *p) try {
     int cur = -1;
     FLEX_HIP_TRY(hipGetDevice(&cur));
     if (cur != p->device) FLEX_HIP_TRY(hipSetDevice(p->device));
-    std::vector<uint2> rec(p->n_records);
-    std::vector<uint32_t> t_beg(static_cast<size_t>(p->n_tasks) + 1), t_dst(p->n_tasks), piece_row(p->n_partials);
+    std::vector<uint2> rec(p->n_records), t_aux(p->n_tasks);
+    std::vector<uint32_t> t_beg(static_cast<size_t>(p->n_tasks) + 1), t_dst(p->n_tasks);
     std::vector<uint4> chunk(p->n_slots);
     std::vector<SplitRow> split(p->n_split);
     auto down = [&](void *dst, const void *src, size_t bytes) { return bytes == 0 || hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess; };
     const bool ok_copy = down(rec.data(), p->d_rec, rec.size() * sizeof(uint2)) && down(t_beg.data(), p->d_t_beg, t_beg.size() * 4) &&
                          down(t_dst.data(), p->d_t_dst, t_dst.size() * 4) && down(chunk.data(), p->d_chunk, chunk.size() * sizeof(uint4)) &&
-                         down(split.data(), p->d_split, split.size() * sizeof(SplitRow)) && down(piece_row.data(), p->d_piece_row, piece_row.size() * 4);
+                         down(split.data(), p->d_split, split.size() * sizeof(SplitRow)) && down(t_aux.data(), p->d_t_aux, t_aux.size() * sizeof(uint2));
     if (cur != p->device) (void)hipSetDevice(cur);
     if (!ok_copy) return FLEX_ERR_HIP;
 
@@ -672,24 +897,27 @@ int flex_plan_self_check(const flex_plan *p) try {
         const uint64_t col = p->off32 ? r.x / row_bytes : r.x;
         if (col >= static_cast<uint64_t>(p->n) || (p->off32 && r.x % row_bytes != 0)) return FLEX_ERR_FORMAT;
     }
-    // every C row exactly once; pieces of a split row are consecutive tasks on consecutive partial slots
-    std::vector<uint8_t> written(static_cast<size_t>(p->c_rows), 0);
-    uint32_t next_partial = 0;
+    // every C row exactly once: by one task, or by one split row whose pieces own consecutive partial slots; every
+    // partial slot is written by exactly one task, and that task names its row and the row's piece count (t_aux:
+    // what the arrival counter is compared with).  Pieces of a row need NOT be consecutive tasks (2-D schedules).
+    std::vector<uint8_t> written(static_cast<size_t>(p->c_rows), 0), slot_taken(p->n_partials, 0);
     for (uint32_t t = 0; t < p->n_tasks; ++t) {
         const uint32_t d = t_dst[t];
         if (d & kPartialFlag) {
-            if ((d & ~kPartialFlag) != next_partial++) return FLEX_ERR_FORMAT;
+            const uint32_t ps = d & ~kPartialFlag;
+            if (ps >= p->n_partials || slot_taken[ps]++) return FLEX_ERR_FORMAT;
+            const uint2 a = t_aux[t];
+            if (a.x >= p->n_split || a.y != split[a.x].count || ps < split[a.x].first || ps >= split[a.x].first + split[a.x].count) return FLEX_ERR_FORMAT;
         } else {
             if (d >= p->c_rows || written[d]++) return FLEX_ERR_FORMAT;
         }
     }
-    if (next_partial != p->n_partials) return FLEX_ERR_FORMAT;
+    for (uint8_t w : slot_taken)
+        if (w != 1) return FLEX_ERR_FORMAT;
     uint32_t first = 0;
     for (uint32_t i = 0; i < p->n_split; ++i) {
         const SplitRow &sr = split[i];
-        if (sr.first != first || sr.count < 1 || sr.row >= p->c_rows || written[sr.row]++) return FLEX_ERR_FORMAT;
-        for (uint32_t j = 0; j < sr.count; ++j)
-            if (piece_row[sr.first + j] != i) return FLEX_ERR_FORMAT;
+        if (sr.first != first || sr.count < 2 || sr.row >= p->c_rows || written[sr.row]++) return FLEX_ERR_FORMAT;
         first += sr.count;
     }
     if (first != p->n_partials) return FLEX_ERR_FORMAT;

@@ -153,6 +153,51 @@ __device__ __forceinline__ void store_row_out(float *ptr, const RowOut<G> &o) {
     }
 }
 
+// All-reduce form for every G: afterwards EVERY lane holds the sum over the S slots of its 4 columns, so the lanes of
+// slot 0 can write the row as contiguous float4s.  Used for pieces (partial sums of rows that other chunks hold pieces
+// of): their stores are write-through (sc1), and a 4-byte sc1 store costs ~6x a 16-byte one per byte
+// (MI355X_MICROARCH.md, stores of each flavour), so the scattered G=8 form of RowOut is not used there.
+template <int G>
+__device__ __forceinline__ float4 reduce_full(const float4 &acc) {
+    float4 r = acc;
+    if constexpr (G <= 8) {  // lane ^ 8 inside each 16-lane row: row_ror:8
+        r.x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r.x), 0x128, 0xf, 0xf, false));
+        r.y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r.y), 0x128, 0xf, 0xf, false));
+        r.z += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r.z), 0x128, 0xf, 0xf, false));
+        r.w += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r.w), 0x128, 0xf, 0xf, false));
+    }
+    if constexpr (G <= 16) {
+        r.x = pair16(r.x, r.x);
+        r.y = pair16(r.y, r.y);
+        r.z = pair16(r.z, r.z);
+        r.w = pair16(r.w, r.w);
+    }
+    if constexpr (G <= 32) {
+        r.x = pair32(r.x, r.x);
+        r.y = pair32(r.y, r.y);
+        r.z = pair32(r.z, r.z);
+        r.w = pair32(r.w, r.w);
+    }
+    return r;
+}
+
+// 16-byte agent-scope (sc1) load through a 64-bit address: served by the L2, never by this CU's L1.  The compiler does
+// not count loads issued from inline asm, so the caller waits with wait_loads() before touching the values.
+__device__ __forceinline__ v4f load_b128_sc1(const float *ptr) {
+    v4f v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_loads(v4f (&v)[N]) {
+    static_assert(N == 8, "one batch of the piece sum");
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                 :
+                 : "memory");
+}
+
 constexpr int kWindowRecs = 256;  // records staged per wave and window (2 KiB of LDS)
 
 [[maybe_unused]] __device__ __forceinline__ uint32_t xcc_id() {
@@ -197,7 +242,7 @@ __device__ __forceinline__ void stage_window(uint2 *my_lds, const uint2 *__restr
 // All the work of one chunk once its header {first task, #tasks, first record, end record} and its
 // task descriptors (lane i: t_beg[t0+i], t_dst[t0+i]) are in registers.
 template <int G, bool OFF32, int U>
-__device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint32_t my_beg, uint32_t my_dst,
+__device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint32_t my_beg, uint32_t my_dst, uint2 my_aux,
                                               uint2 *my_lds, const char *__restrict__ Bb,
                                               float *__restrict__ C, int lane, int c0, bool col_ok
 #ifdef FLEX_TRACE
@@ -222,30 +267,40 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
     float4 acc = {0.f, 0.f, 0.f, 0.f};
     const int out_col = row_out_col<G>(lane, c0);              // first column this lane stores of a finished row
     const bool out_ok = col_ok && row_out_lane<G>(lane);
-    // A piece of a split row is a chunk of its own (planner invariant): its single task is never flushed in
-    // the loops; the sum is reduced and combined after them, where the gather registers are dead.
-    const uint32_t dst0 = __builtin_amdgcn_readlane(my_dst, 0);
-    const bool piece = nt == 1 && (dst0 & kPartialFlag) != 0;
-
     // Write out the task that ends at the current stream position (and any empty rows behind it).
     // row_end is kept at ~0 once the chunk's tasks are exhausted, so the per-step test in the hot
-    // loop is ONE scalar compare.
+    // loop is ONE scalar compare.  A task whose destination carries kPartialFlag is a PIECE: one of several
+    // partial sums of a C row (a row longer than one budget, or a row cut by column panel, plan.cpp); it goes to
+    // its k-wide slot of `partial`, write-through when the pieces are combined inside this launch.
     auto flush = [&](uint32_t pos) {
         do {
-            const RowOut<G> o = reduce_row<G>(acc);
             const uint32_t dst = __builtin_amdgcn_readlane(my_dst, ti);
+            if (dst & kPartialFlag) {  // wave-uniform
+                const float4 r = reduce_full<G>(acc);
+                float *prow = p.partial + static_cast<uint64_t>(dst & ~kPartialFlag) * k;  // uniform
+                if (slot == 0 && col_ok) {
+                    if (p.fused_fixup) {
+                        const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(prow, 0, k * 4, 0x00020000);
+                        const v4u pv = {__float_as_uint(r.x), __float_as_uint(r.y), __float_as_uint(r.z), __float_as_uint(r.w)};
+                        __builtin_amdgcn_raw_buffer_store_b128(pv, prsrc, c0 * 4, 0, 16 /* sc1 */);
+                    } else {  // combined by spmm_fixup_kernel after this launch
+                        *reinterpret_cast<float4 *>(prow + c0) = r;
+                    }
+                }
+            } else {
+                const RowOut<G> o = reduce_row<G>(acc);
 #ifdef FLEX_ABL_NOSTORE  // timing-only ablation: the store is kept in the code but never executes
-            if (out_ok && p.k < 0)
+                if (out_ok && p.k < 0)
 #else
-            if (out_ok)
+                if (out_ok)
 #endif
-                store_row_out<G>(C + static_cast<uint64_t>(dst) * ldc + out_col, o);
+                    store_row_out<G>(C + static_cast<uint64_t>(dst) * ldc + out_col, o);
+            }
             acc = {0.f, 0.f, 0.f, 0.f};
             ++ti;
             row_end = ti < nt ? __builtin_amdgcn_readlane(my_beg, ti + 1) : 0xFFFFFFFFu;
         } while (row_end == pos);
     };
-    if (piece) row_end = 0xFFFFFFFFu;
     if (nt == 0) row_end = 0xFFFFFFFFu;
     if (row_end == zb) flush(zb);  // leading empty rows
 
@@ -314,68 +369,69 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
         }
     }
 #ifdef FLEX_ABL_NOFLUSH
-    // pos != the ~0 sentinel, or the do-while never ends; a piece's task is reduced below, not flushed (its dst is a
-    // partial-slot id, not a C row)
-    if (nt > 0 && !piece) { ti = nt - 1; flush(0xFFFFFFFEu); }
+    // pos != the ~0 sentinel, or the do-while never ends
+    if (nt > 0) { ti = nt - 1; flush(0xFFFFFFFEu); }
 #endif
-    if (piece) {
-        const RowOut<G> o = reduce_row<G>(acc);
-        const uint32_t ps = dst0 & ~kPartialFlag;
-        if (!p.fused_fixup) {  // partial sums are combined by spmm_fixup_kernel after this launch
-            if (out_ok) {
-                float *pp = p.partial + static_cast<uint64_t>(ps) * k + out_col;
+    // Pieces are combined INSIDE this launch by whichever piece arrives last (cdna guide G16, counter form with
+    // write-through payload): (1) every partial sum of this chunk was stored write-through (sc1), so it is at
+    // device scope once the store completes; (2) the wave drains its stores; (3) lane i bumps the arrival counter of
+    // task i's row (agent-scope atomic; t_aux = {row's index in `split`, #pieces}); (4) a lane whose add returns
+    // count-1 knows every piece of that row is visible: the wave reads them with sc1 loads (never through a CU's
+    // L1) and adds them in PIECE order -- the sum is reproducible although the reducer is not -- S rows at a time,
+    // one per slot, and re-arms the counters for the next launch.
+    // Why RELAXED + sc1 instead of an acq_rel atomic: a release at agent scope is `buffer_wbl2 sc1`, a
+    // write-back of the whole XCD L2 (1.7-6.5 us, MI355X_MICROARCH.md "Workgroup dispatch ... visibility"),
+    // paid by every chunk.  The form used here is that guide's hand-off "each storing wave for itself:
+    // sc1 stores of whole 16-B granules -> the wave's own s_waitcnt vmcnt(0) -> agent-scope atomic add;
+    // the wave whose add returned last reads every byte with ... sc1 loads" (its measured table of sc1
+    // hand-offs on gfx950 / ROCm 7.2; measured, not an architectural guarantee, hence the 300-launch
+    // test under uneven load, tests/test_gpu_spmm.py).  The workspace makes a plan non-reentrant: one
+    // launch of a plan at a time (include/flex_spmm.h, flex_spmm).
+    const bool mine_partial = static_cast<uint32_t>(lane) < nt && (my_dst & kPartialFlag) != 0;
+    if (p.fused_fixup && __builtin_amdgcn_ballot_w64(mine_partial) != 0) {  // wave-uniform
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t arrived = 0;
+        if (mine_partial)
+            arrived = __hip_atomic_fetch_add(p.split_cnt + static_cast<uint64_t>(my_aux.x) * gridDim.y + blockIdx.y, 1u,
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t done = __builtin_amdgcn_ballot_w64(mine_partial && arrived + 1 == my_aux.y);
+        while (done != 0) {  // wave-uniform: up to S completed rows per round, slot s takes the s-th
+            int take = -1;
 #pragma unroll
-                for (int i = 0; i < RowOut<G>::kVals; ++i) pp[i] = o.v[i];
-            }
-        } else {
-            // Combined inside this launch by whichever piece finishes LAST (cdna guide G16, counter form
-            // with write-through payload): (1) the partial sum is stored write-through (sc1), so it is at
-            // device scope when the store completes; (2) this wave drains its stores; (3) one lane bumps
-            // the row's arrival counter (agent-scope atomic); (4) the wave whose add returns count-1 knows
-            // every piece is visible, reads all of them with sc1 loads (never through its CU's L1) and
-            // adds them in PIECE order -- the sum is reproducible although the reducer is not -- and
-            // re-arms the counter for the next launch.
-            const auto prsrc = __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, p.partial_bytes, 0x00020000);
-            if (out_ok) {
-                const uint32_t off = (ps * k + out_col) * 4u;
-                if constexpr (RowOut<G>::kVals == 4) {
-                    const v4u pv = {__float_as_uint(o.v[0]), __float_as_uint(o.v[1]), __float_as_uint(o.v[2]), __float_as_uint(o.v[3])};
-                    __builtin_amdgcn_raw_buffer_store_b128(pv, prsrc, off, 0, 16 /* sc1 */);
-                } else {
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o.v[0]), prsrc, off, 0, 16 /* sc1 */);
+            for (int s2 = 0; s2 < S; ++s2) {
+                if (done != 0) {
+                    const int i = __builtin_ctzll(done);
+                    done &= done - 1;
+                    if (slot == s2) take = i;
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const uint32_t sidx = p.piece_row[ps];
-            const SplitRow sr = p.split[sidx];
-            uint32_t *cnt = p.split_cnt + static_cast<uint64_t>(sidx) * gridDim.y + blockIdx.y;
-            uint32_t arrived = 0;
-            if (lane == 0) arrived = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            arrived = __builtin_amdgcn_readfirstlane(arrived);
-            if (arrived == sr.count - 1) {
-                float4 s4 = {0.f, 0.f, 0.f, 0.f};
-                if (slot == 0 && col_ok) {
+            const uint32_t sidx = __shfl(my_aux.x, take < 0 ? 0 : take);
+            if (take >= 0) {
+                const SplitRow sr = p.split[sidx];
+                if (col_ok) {
+                    const float *base = p.partial + static_cast<uint64_t>(sr.first) * k + c0;
+                    float4 s4 = {0.f, 0.f, 0.f, 0.f};
                     for (uint32_t j = 0; j < sr.count; j += 8) {
-                        v4u v[8];
+                        v4f v[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const uint32_t jj = min(j + u, sr.count - 1);
-                            v[u] = __builtin_amdgcn_raw_buffer_load_b128(prsrc, ((sr.first + jj) * k + c0) * 4u, 0, 16 /* sc1 */);
-                        }
+                        for (int u = 0; u < 8; ++u) v[u] = load_b128_sc1(base + static_cast<uint64_t>(min(j + u, sr.count - 1)) * k);
+                        wait_loads(v);
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             if (j + u < sr.count) {
-                                s4.x += __uint_as_float(v[u].x);
-                                s4.y += __uint_as_float(v[u].y);
-                                s4.z += __uint_as_float(v[u].z);
-                                s4.w += __uint_as_float(v[u].w);
+                                s4.x += v[u].x;
+                                s4.y += v[u].y;
+                                s4.z += v[u].z;
+                                s4.w += v[u].w;
                             }
                         }
                     }
                     const v4f val = {s4.x, s4.y, s4.z, s4.w};
                     __builtin_nontemporal_store(val, reinterpret_cast<v4f *>(C + static_cast<uint64_t>(sr.row) * ldc + c0));
                 }
-                if (lane == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane % G == 0)
+                    __hip_atomic_store(p.split_cnt + static_cast<uint64_t>(sidx) * gridDim.y + blockIdx.y, 0u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -409,7 +465,8 @@ __global__ __launch_bounds__(64 * WPB) void spmm_flat_kernel(PlanView p, const f
     const uint4 hdr = p.chunk[chunk];
     const uint32_t my_beg = (static_cast<uint32_t>(lane) <= hdr.y) ? p.t_beg[hdr.x + lane] : 0u;
     const uint32_t my_dst = (static_cast<uint32_t>(lane) < hdr.y) ? p.t_dst[hdr.x + lane] : 0u;
-    compute_chunk<G, OFF32, U>(p, hdr, my_beg, my_dst, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok, phase, last_);
+    const uint2 my_aux = (static_cast<uint32_t>(lane) < hdr.y) ? p.t_aux[hdr.x + lane] : make_uint2(0u, 0u);
+    compute_chunk<G, OFF32, U>(p, hdr, my_beg, my_dst, my_aux, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok, phase, last_);
     if (lane == 0 && p.trace != nullptr) {
         uint64_t *log = p.trace + static_cast<uint64_t>(chunk) * 12;
         log[0] = xcc_id();
@@ -431,7 +488,8 @@ __global__ __launch_bounds__(64 * WPB) void spmm_flat_kernel(PlanView p, const f
     if (hdr.y == 0) return;  // an empty entry that pads this XCD's slice of the table (plan.cpp)
     const uint32_t my_beg = (static_cast<uint32_t>(lane) <= hdr.y) ? p.t_beg[hdr.x + lane] : 0u;
     const uint32_t my_dst = (static_cast<uint32_t>(lane) < hdr.y) ? p.t_dst[hdr.x + lane] : 0u;
-    compute_chunk<G, OFF32, U>(p, hdr, my_beg, my_dst, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok);
+    const uint2 my_aux = (static_cast<uint32_t>(lane) < hdr.y) ? p.t_aux[hdr.x + lane] : make_uint2(0u, 0u);  // read at chunk end only
+    compute_chunk<G, OFF32, U>(p, hdr, my_beg, my_dst, my_aux, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok);
 #endif
 }
 

@@ -16,9 +16,12 @@
 #include <stdexcept>
 #include <vector>
 
+#include "host_parallel.h"
 #include "internal.h"
 
 namespace {
+
+using flex::parallel_chunks;
 
 inline uint64_t mix64(uint64_t x) {  // splitmix64 finaliser
     x += 0x9E3779B97F4A7C15ull;
@@ -33,29 +36,6 @@ struct Rng {
     uint64_t next() { return mix64(s++); }
     double uni() { return static_cast<double>(next() >> 11) * (1.0 / 9007199254740992.0); }  // [0,1)
 };
-
-int host_threads() {
-    long t = 0;
-    if (const char *e = std::getenv("FLEX_HOST_THREADS")) t = std::strtol(e, nullptr, 10);
-    if (t <= 0) t = static_cast<long>(std::thread::hardware_concurrency());
-    return static_cast<int>(std::clamp<long>(t, 1, 32));
-}
-
-template <typename F>
-void parallel_chunks(int64_t nchunks, F &&fn) {
-    const int nt = static_cast<int>(std::min<int64_t>(host_threads(), nchunks));
-    if (nt <= 1) {
-        for (int64_t c = 0; c < nchunks; ++c) fn(c);
-        return;
-    }
-    std::atomic<int64_t> next{0};
-    std::vector<std::thread> th;
-    for (int t = 0; t < nt; ++t)
-        th.emplace_back([&] {
-            for (int64_t c; (c = next.fetch_add(1)) < nchunks;) fn(c);
-        });
-    for (auto &t : th) t.join();
-}
 
 // sort + unique of 64-bit keys whose high word is < n: bucket by high word, sort buckets in parallel
 void sort_unique(std::vector<uint64_t> &keys, uint64_t n) {

@@ -67,6 +67,7 @@ typedef struct flex_plan flex_plan;
                                      widths too (same row schedule), time each on zero-filled operands of the real
                                      size, keep the fastest.  Costs two extra plans and, for the duration of the call,
                                      device memory for one B and one C */
+#define FLEX_PLAN_ROW_RANGE 0x1000u /* flex_plan_create_ex only: desc->row_begin/row_end name a row shard */
 
 /* ≙ Mat::Mat + csr2_DiagTiling + alpha_transfer (mat.cu:7-31, 680-942, 268-293):
  * builds the row-panel plan for `hostA` and uploads it to `device`.  The reference's
@@ -100,7 +101,8 @@ int flex_plan_create_rows(flex_plan **out, const flex_csr *hostA, int64_t row_be
 /* Every option of the four entry points above in one call (they are thin wrappers over it), for the combinations
  * they do not name -- e.g. a row shard of a reordered matrix over padded storage.  Zero-initialise, set
  * struct_size = sizeof(flex_plan_desc), fill what is needed:
- *   row_begin/row_end  0/0 = all rows; otherwise the shard [row_begin,row_end) (flags must be FLEX_ORDER_NATURAL)
+ *   row_begin/row_end  read only when flags has FLEX_PLAN_ROW_RANGE: the shard [row_begin,row_end), which may be
+ *                      empty (the order bits must then be FLEX_ORDER_NATURAL); without the flag: all rows
  *   col_map            column c of A reads B row col_map[c] (NULL = c)
  *   row_map            row r of A writes C row row_map[r] (NULL = r - row_begin); all rows only, A square
  *   ldb/ldc            row strides of B and C in floats (0 = k) */
@@ -118,7 +120,11 @@ int flex_plan_create_ex(flex_plan **out, const flex_plan_desc *desc);
  * dB: n x k row-major device fp32; dC: m x k row-major device fp32, fully overwritten
  * (alpha=1, beta=0 as in cuSpmm, flex.cu:5728-5729).  Asynchronous on `stream`;
  * no allocation, no host sync (safe to capture in a hipGraph).  dB/dC must be
- * 16-byte aligned when k % 4 == 0. */
+ * 16-byte aligned when k % 4 == 0.
+ * NOT re-entrant per plan: a plan owns the partial-sum workspace and arrival counters of its split
+ * rows, so at most ONE launch of a given plan may be in flight -- do not enqueue the same plan on two
+ * streams, or replay two graphs holding it, concurrently (successive launches on one stream are fine;
+ * different plans are independent).  Nothing checks this; overlapping launches corrupt split rows. */
 int flex_spmm(flex_plan *plan, const float *dB, float *dC, flex_stream_t stream);
 
 /* ≙ alpha_freeMatGPU (mat.cuh:184-193). */
@@ -136,6 +142,8 @@ typedef struct flex_plan_info {
     int32_t order;        /* FLEX_ORDER_* actually applied */
     double plan_ms;       /* host time spent planning + uploading */
     int64_t n_slots;      /* chunk-table entries launched: n_chunks + the empty entries that pad the XCD slices */
+    int32_t two_d;        /* 1: rows are cut by column panel as well (each XCD slice runs phase by phase), else 0 */
+    int32_t panel_rows;   /* two_d: B rows per column panel (a power of two), else 0 */
 } flex_plan_info;
 int flex_plan_get_info(const flex_plan *plan, flex_plan_info *out);
 

@@ -81,6 +81,13 @@ def test_ingest_errors(tmp_path):
     junk.write_text("0,x\n0\n1.0\n")
     with pytest.raises(flex_amd.FlexError):
         flex_amd.csv_load(str(junk))
+    # indices that do not fit 32 bits, or are negative, must fail (std::stoi throws; DataLoader.cu:21-33) instead of
+    # wrapping into a valid-looking index: 4294967297 would otherwise read as column 1
+    for text in ("0,1\n4294967297\n1.0\n", "0,1\n-1\n1.0\n", "0,4294967297\n0\n1.0\n", "0,1\n99999999999999999999\n1.0\n"):
+        wrap = tmp_path / "wrap.csv"
+        wrap.write_text(text)
+        with pytest.raises(flex_amd.FlexError, match="does not parse"):
+            flex_amd.csv_load(str(wrap))
 
 
 def test_amazon_rule_and_rand_fill(tmp_path):

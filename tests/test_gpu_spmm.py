@@ -674,5 +674,121 @@ def test_general_entry_point_covers_combinations():
     v = a.view()
     bad = binding._PlanDesc(8, C.pointer(v), k, 0, 0, 0, 0, 0, 0, None, None)  # wrong struct_size
     assert binding.lib().flex_plan_create_ex(C.byref(h), C.byref(bad)) == -1
-    shard_ordered = binding._PlanDesc(C.sizeof(binding._PlanDesc), C.pointer(v), k, 0, 0, 0, flex_amd.FLEX_ORDER_RCM, 0, 100, None, None)
+    shard_ordered = binding._PlanDesc(C.sizeof(binding._PlanDesc), C.pointer(v), k, 0, 0, 0, flex_amd.FLEX_ORDER_RCM | flex_amd.FLEX_PLAN_ROW_RANGE, 0, 100, None, None)
     assert binding.lib().flex_plan_create_ex(C.byref(h), C.byref(shard_ordered)) == -1  # reorder first, then shard
+    # an EMPTY shard [0,0) through the general entry point is a plan over zero rows (it used to mean "all rows",
+    # and flex_spmm then wrote m rows into a zero-row C): nothing is launched, nothing is written
+    pe = Plan(ap, k, rows=(0, 0), col_map=vo, ldb=ldb, ldc=ldc)
+    assert pe.info()["m"] == 0 and pe.info()["nnz"] == 0
+    guard = torch.full((4, ldc), 5.0, dtype=torch.float32, device="cuda")
+    pe.spmm(Bd.data_ptr(), guard.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.all(guard == 5.0)
+    # zero-initialised descriptor (no FLEX_PLAN_ROW_RANGE) = all rows
+    allrows = binding._PlanDesc(C.sizeof(binding._PlanDesc), C.pointer(v), k, 0, 0, 0, 0, 0, 0, None, None)
+    assert binding.lib().flex_plan_create_ex(C.byref(h), C.byref(allrows)) == 0
+    info = binding._PlanInfo()
+    binding.lib().flex_plan_get_info(h, C.byref(info))
+    assert info.m == a.m
+    binding.lib().flex_plan_destroy(h)
+
+
+@pytest.mark.parametrize("k,lanes", [(32, 0), (64, 0), (128, 0), (128, 8), (128, 32), (256, 0), (100, 0), (36, 0), (7, 0)])
+@pytest.mark.parametrize("order", [FLEX_ORDER_NATURAL, flex_amd.FLEX_ORDER_CLUSTER])
+def test_two_d_column_panel_schedule(monkeypatch, k, lanes, order):
+    """FLEX_2D=1: every XCD slice of the rows is walked column panel by column panel; a row with records in several
+    panels is summed from several pieces (partial slots + arrival counters, many pieces per chunk).  Tiny panels force
+    many phases on a small graph: resCheck against the oracle, the plan self-check, bit-identical repeat launches,
+    and the same bits from the two-launch form (spmm_fixup_kernel adds the pieces in the same order)."""
+    a = flex_amd.synth_graph(n=6000, nnz=6000 + 2 * 90000, community=200, p_in=0.55, p_near=0.3, seed=5)
+    B = random_B(a.n, k, 9)
+    monkeypatch.setenv("FLEX_2D", "1")
+    monkeypatch.setenv("FLEX_PANEL_KB", "32")
+    monkeypatch.setenv("FLEX_SEG_MIN", "2")
+    if lanes:
+        monkeypatch.setenv("FLEX_LANES", str(lanes))
+    p = Plan(a, k, order=order)
+    info = p.info()
+    assert info["two_d"] == 1 and info["panel_rows"] >= 32 and info["n_split_rows"] > a.m // 2 and info["n_partials"] > a.m
+    p.self_check()
+    C1 = run_plan(p, B)
+    assert_matches_oracle(a, B, C1)
+    assert np.array_equal(C1, run_plan(p, B))  # counters re-armed, same piece order
+    monkeypatch.setenv("FLEX_FUSED_FIXUP", "2")
+    p2 = Plan(a, k, order=order)
+    assert np.array_equal(C1, run_plan(p2, B))
+    monkeypatch.delenv("FLEX_FUSED_FIXUP")
+    # against the 1-D schedule of the same matrix: same tolerance, not the same bits
+    monkeypatch.setenv("FLEX_2D", "2")
+    p1 = Plan(a, k, order=order)
+    assert p1.info()["two_d"] == 0
+    assert oracle.rescheck(run_plan(p1, B), C1, a.rowPtr)[0] == 0
+
+
+def test_two_d_with_hubs_empty_rows_shards_and_strides(monkeypatch):
+    """2-D plans of awkward inputs: hub rows (runs longer than a budget inside a panel), empty rows, a rectangular
+    matrix, row shards with a column map, padded storage."""
+    monkeypatch.setenv("FLEX_2D", "1")
+    monkeypatch.setenv("FLEX_PANEL_KB", "64")
+    a = random_csr(5000, 5000, 25, seed=77, long_rows={3: 4500, 2500: 1800, 4999: 700}, empty_frac=0.1)
+    for k, ldb, ldc in ((128, None, None), (64, 96, 68)):
+        B = random_B(a.n, ldb or k, 3)
+        p = Plan(a, k, ldb=ldb, ldc=ldc) if ldb else Plan(a, k)
+        assert p.info()["two_d"] == 1
+        p.self_check()
+        if ldb:
+            Cd = torch.full((a.m, ldc), 2.5, device="cuda")
+            p.spmm(dev(B).data_ptr(), Cd.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            C = Cd.cpu().numpy()
+            assert np.all(C[:, k:] == 2.5)
+            assert_matches_oracle(a, np.ascontiguousarray(B[:, :k]), np.ascontiguousarray(C[:, :k]))
+        else:
+            assert_matches_oracle(a, B, run_plan(p, B))
+    rect = random_csr(3000, 9000, 40, seed=78, long_rows={5: 6000})
+    Br = random_B(rect.n, 128, 4)
+    pr = Plan(rect, 128)
+    pr.self_check()
+    assert_matches_oracle(rect, Br, run_plan(pr, Br))
+    # row shards of a reordered matrix (what one GPU of a row-sharded run plans)
+    g = flex_amd.synth_graph(n=8000, nnz=8000 + 2 * 150000, community=256, p_in=0.6, p_near=0.25, seed=6)
+    Bg = random_B(g.n, 128, 5)
+    gold = oracle.spmm(g.rowPtr, g.col, g.vals, Bg, nthreads=8)
+    got = np.zeros_like(gold)
+    for r in range(3):
+        sh = flex_amd.make_shard(g, 128, r, 3, order="cluster")
+        ps = sh.plan(128, 0)
+        assert ps.info()["two_d"] == 1
+        ps.self_check()
+        got[sh.original_rows()] = run_plan(ps, Bg)
+    assert oracle.rescheck(gold, got, g.rowPtr)[0] == 0
+
+
+def test_two_d_reduction_is_stable_under_repetition(monkeypatch):
+    """The in-launch combination now runs for pieces scattered over many chunks (several arrivals per chunk, up to S
+    rows completed per round): 200 launches under uneven load must give the same bits and the right answer."""
+    monkeypatch.setenv("FLEX_2D", "1")
+    monkeypatch.setenv("FLEX_PANEL_KB", "64")
+    monkeypatch.setenv("FLEX_SEG_MIN", "2")
+    a = flex_amd.synth_graph(n=40000, nnz=40000 + 2 * 1500000, community=512, p_in=0.5, p_near=0.3, seed=8)
+    k = 128
+    Bn = random_B(a.n, k, 92)
+    B = dev(Bn)
+    p = Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER)
+    info = p.info()
+    assert info["two_d"] == 1 and info["n_split_rows"] > 30000
+    ref = p(B).clone()
+    torch.cuda.synchronize()
+    assert_matches_oracle(a, Bn, ref.cpu().numpy(), nthreads=8)
+    C = torch.empty_like(ref)
+    filler = torch.empty(64 << 20, device="cuda")
+    for it in range(200):
+        C.fill_(float("nan"))
+        if it % 3 == 0:
+            filler.add_(1.0)
+        p(B, out=C)
+        if it % 25 == 24 or it < 4:
+            torch.cuda.synchronize()
+            assert torch.equal(C, ref), f"launch {it}: result changed"
+    torch.cuda.synchronize()
+    assert torch.equal(C, ref)

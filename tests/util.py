@@ -43,3 +43,29 @@ def assert_matches_oracle(a, B, C_hip, nthreads=4):
     cnt, max_err, me_nnz, _ = oracle.rescheck(gold, C_hip, a.rowPtr)
     assert cnt == 0, f"{cnt} elements beyond 4*eps*row_nnz (max err {max_err:g} on a row of {me_nnz} nnz)"
     return gold, max_err
+
+
+def vendor_spmm(a, k, B):
+    """hipSPARSE CSR_ALG3 row-major SpMM through libflex_vendor.so (≙ cuSpmm, flex.cu:5717-5804): returns C (numpy)."""
+    import ctypes as C
+    import os
+
+    import torch
+
+    import flex_amd
+    V = C.CDLL(os.path.join(os.path.dirname(flex_amd.lib_path()), "libflex_vendor.so"))
+    V.flex_vendor_spmm_create.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int64, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    V.flex_vendor_spmm_run.argtypes = [C.c_void_p, C.c_void_p]
+    V.flex_vendor_spmm_destroy.argtypes = [C.c_void_p]
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()  # noqa: E731
+    rp, col, val = dev(a.rowPtr.astype(np.int32)), dev(a.col.astype(np.int32)), dev(a.vals)
+    Bd = dev(B)
+    Cd = torch.zeros((a.m, k), device="cuda")
+    h = C.c_void_p()
+    assert V.flex_vendor_spmm_create(C.byref(h), a.m, a.n, a.nnz, rp.data_ptr(), col.data_ptr(), val.data_ptr(), k,
+                                     Bd.data_ptr(), Cd.data_ptr()) == 0
+    assert V.flex_vendor_spmm_run(h, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    V.flex_vendor_spmm_destroy(h)
+    return Cd.cpu().numpy()
