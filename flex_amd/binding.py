@@ -50,7 +50,8 @@ class _PlanInfo(C.Structure):  # flex_plan_info
                 ("nnz", C.c_int64), ("n_tasks", C.c_int64), ("n_chunks", C.c_int64),
                 ("n_split_rows", C.c_int64), ("n_partials", C.c_int64),
                 ("device_bytes", C.c_int64), ("lanes_per_nz", C.c_int32), ("order", C.c_int32),
-                ("plan_ms", C.c_double), ("n_slots", C.c_int64), ("two_d", C.c_int32), ("panel_rows", C.c_int32)]
+                ("plan_ms", C.c_double), ("n_slots", C.c_int64), ("two_d", C.c_int32), ("panel_rows", C.c_int32),
+                ("n_tiles", C.c_int64), ("tile_nnz", C.c_int64)]
 
 
 class _PlanStats(C.Structure):  # flex_plan_stats
@@ -59,7 +60,9 @@ class _PlanStats(C.Structure):  # flex_plan_stats
                 ("reuse_xcd", C.c_double), ("gather_bytes", C.c_double), ("l2_bytes", C.c_double),
                 ("chunk_rec_max", C.c_int64), ("chunk_rec_mean", C.c_double),
                 ("chunk_imb_pct", C.c_double), ("xcd_imb_pct", C.c_double),
-                ("split_nnz_pct", C.c_double), ("pad_pct", C.c_double), ("n_workgroups", C.c_int64)]
+                ("split_nnz_pct", C.c_double), ("pad_pct", C.c_double), ("n_workgroups", C.c_int64),
+                ("tile_nnz_pct_10", C.c_double), ("tile_nnz_pct_25", C.c_double), ("tile_nnz_pct_50", C.c_double),
+                ("tile_mean_fill", C.c_double), ("mfma_tiles", C.c_int64), ("mfma_nnz_pct", C.c_double)]
 
 
 class _PlanDesc(C.Structure):  # flex_plan_desc

@@ -58,4 +58,8 @@ void Mat::alpha_stats_collect(FILE *stream) const {
                  flex_plan_self_check(plan) == FLEX_OK ? "ok" : "FAILED");
     std::fprintf(stream, " B reuse: wave %.2f, workgroup %.2f, XCD %.2f; gather model %.1f MB, L2 model %.1f MB.\n",
                  s.reuse_wave, s.reuse_wg, s.reuse_xcd, s.gather_bytes * 1e-6, s.l2_bytes * 1e-6);
+    // the block-density detector's verdict (north_star's MFMA clause): nonzeros by the fill of their 32x32 tile, and what was routed
+    std::fprintf(stream, " Dense tiles: mean fill %.4f; %.1f%% of nnz in tiles of fill >= 0.10, %.1f%% >= 0.25, %.1f%% >= 0.50; MFMA route: %lld tiles, %.1f%% of nnz%s.\n",
+                 s.tile_mean_fill, s.tile_nnz_pct_10, s.tile_nnz_pct_25, s.tile_nnz_pct_50, static_cast<long long>(s.mfma_tiles), s.mfma_nnz_pct,
+                 s.mfma_tiles ? "" : " (vector kernel only)");
 }

@@ -34,6 +34,15 @@ struct PlanView {
 };
 
 
+// What the dense-tile kernel reads (tile_kernels.hip): 32x32 blocks of A that left the record stream.
+struct TileView {
+    const float *a;            // [n_tiles][4][64][4] tile values in MFMA A-operand order: (q,lane,e) = A[lane&31][2(4q+e) + (lane>>5)]
+    const uint32_t *boff;      // [n_tiles][32] B row of each tile column: byte offset (off32) or row id
+    const uint32_t *rt_ptr;    // [n_row_tiles+1] tiles of each listed row tile, in column order
+    const uint32_t *rt_rows;   // [n_row_tiles][32] C row of each row of the row tile, 0xFFFFFFFF = none
+    uint32_t n_row_tiles;
+};
+
 constexpr uint32_t kPartialFlag = 0x80000000u;
 constexpr int kWavesPerBlock = 4;  // 256-thread workgroups
 constexpr int kXcds = 8;           // MI355X: 8 XCDs, each with a private 4 MiB L2
@@ -57,6 +66,7 @@ int launch_fixup(const float *partial, const SplitRow *rows, uint32_t n_rows, in
                  hipStream_t s);
 int kernel_attributes(int lanes_per_nz, bool off32, bool vec4, hipFuncAttributes *attr, int *waves_per_cu);
 int launch_gather_rows(float *dst, const float *src, const int32_t *idx, int64_t n, int k, hipStream_t s);
+int launch_tiles(const TileView &tv, bool off32, const float *dB, float *dC, int k, int ldb, int ldc, hipStream_t s);
 
 // host-side helpers shared by the ABI files
 int order_rcm_host(int64_t n, const uint32_t *rowPtr, const uint32_t *col, std::vector<uint32_t> &rank);

@@ -74,6 +74,13 @@ struct flex_plan {
     uint32_t *d_split_cnt = nullptr;
     bool fused_fixup = false;
     bool two_d = false;  // rows cut by column panel (phases), not only by length
+    // dense 32x32 tiles routed to the MFMA kernel (tile_kernels.hip)
+    float *d_tile_a = nullptr;
+    uint32_t *d_tile_boff = nullptr, *d_rt_ptr = nullptr, *d_rt_rows = nullptr;
+    uint32_t n_tiles = 0, n_row_tiles = 0;
+    int64_t tile_nnz = 0;
+    int64_t tile_hist[3] = {0, 0, 0}, tile_cells = 0;  // detector report
+    bool tile_hist_valid = false;
     uint32_t panel_rows = 0;
     uint32_t n_tasks = 0, n_chunks = 0, n_slots = 0, n_split = 0, n_partials = 0;  // n_slots: chunk table incl. padding
     uint64_t n_records = 0;   // nnz + padding
@@ -105,6 +112,10 @@ void free_plan_device(flex_plan *p) {
     (void)hipFree(p->d_partial);
     (void)hipFree(p->d_split);
     (void)hipFree(p->d_split_cnt);
+    (void)hipFree(p->d_tile_a);
+    (void)hipFree(p->d_tile_boff);
+    (void)hipFree(p->d_rt_ptr);
+    (void)hipFree(p->d_rt_rows);
 }
 
 // ≙ alpha_stats_collect (mat.cu:944-1065): distinct B rows per chunk / workgroup / XCD slice by
@@ -136,7 +147,7 @@ void collect_stats(flex_plan *p, const std::vector<uint2> &rec, const std::vecto
     }
     st.records = static_cast<int64_t>(rec.size());
     st.n_workgroups = nblk;
-    const double nnz = static_cast<double>(p->nnz);
+    const double nnz = static_cast<double>(p->nnz - p->tile_nnz);  // what the vector kernel processes
     st.reuse_wave = st.cols_wave ? nnz / st.cols_wave : 0.0;
     st.reuse_wg = st.cols_wg ? nnz / st.cols_wg : 0.0;
     st.reuse_xcd = st.cols_xcd ? nnz / st.cols_xcd : 0.0;
@@ -148,7 +159,150 @@ void collect_stats(flex_plan *p, const std::vector<uint2> &rec, const std::vecto
     st.xcd_imb_pct = st.records ? 100.0 * xmax * kXcds / st.records - 100.0 : 0.0;
     st.split_nnz_pct = nnz > 0 ? 100.0 * split_nnz / nnz : 0.0;
     st.pad_pct = nnz > 0 ? 100.0 * (st.records - nnz) / nnz : 0.0;
+    // detector report + what was routed to the MFMA kernel
+    const double all = static_cast<double>(p->nnz);
+    st.tile_nnz_pct_10 = all > 0 ? 100.0 * p->tile_hist[0] / all : 0.0;
+    st.tile_nnz_pct_25 = all > 0 ? 100.0 * p->tile_hist[1] / all : 0.0;
+    st.tile_nnz_pct_50 = all > 0 ? 100.0 * p->tile_hist[2] / all : 0.0;
+    st.tile_mean_fill = p->tile_cells > 0 ? all / (1024.0 * p->tile_cells) : 0.0;
+    st.mfma_tiles = p->n_tiles;
+    st.mfma_nnz_pct = all > 0 ? 100.0 * p->tile_nnz / all : 0.0;
     p->has_stats = true;
+}
+
+// ---- block-density detector (north_star: "MFMA only where RCM/Gorder reordering yields dense block-sparse tiles").
+// The matrix is looked at in SCHEDULE coordinates: row tile = 32 consecutive rows of the schedule, column tile = 32
+// consecutive column positions.  Every (row tile, column tile) pair with at least one entry is counted; `hist_nnz`
+// reports which share of the nonzeros sits in tiles of fill >= 0.10 / 0.25 / 0.50 (the verdict `flex ... --stats`
+// prints for every graph), and -- when `thr` > 0 -- tiles holding >= thr entries are taken OUT of the record stream
+// (`in_tile[e - e_base] = 1`) and stored as dense fp32 blocks in the A-operand order of v_mfma_f32_32x32x2_f32.
+struct DenseTiles {
+    std::vector<float> a;           // [T][4][64][4]
+    std::vector<uint32_t> boff;     // [T][32]
+    std::vector<uint32_t> rt_ptr;   // [R+1]
+    std::vector<uint32_t> rt_rows;  // [R][32]
+    int64_t nnz = 0;                // entries moved into tiles
+    int64_t hist_nnz[3] = {0, 0, 0};
+    int64_t n_cells = 0;            // (row tile, column tile) pairs with at least one entry
+};
+
+int detect_dense_tiles(const flex_csr *A, int32_t r0, int32_t m, const std::vector<uint32_t> &sched, const std::vector<uint32_t> &colpos,
+                       const int32_t *col_map, const int32_t *dst_map, bool off32, uint32_t row_bytes32, uint32_t thr, int64_t stride,
+                       std::vector<uint8_t> &in_tile, DenseTiles &out) {  // stride > 1: look at every stride-th row tile only (thr must be 0)
+    const uint32_t e_base = A->rowPtr[r0];
+    const int64_t n_rt = (static_cast<int64_t>(m) + 31) / 32;
+    constexpr int64_t kBlk = 64;  // row tiles per work item
+    const int64_t nblk = (n_rt + kBlk - 1) / kBlk;
+    struct Found {
+        uint32_t rt, ct;
+        std::vector<float> a;  // 1024, operand order
+    };
+    std::vector<std::vector<Found>> found(static_cast<size_t>(nblk));
+    std::vector<int64_t> h0(static_cast<size_t>(nblk), 0), h1(h0), h2(h0), cells(h0), moved(h0);
+    std::atomic<int> failed{0};
+    parallel_chunks(nblk, [&](int64_t b) {
+        try {
+            std::vector<uint64_t> key;  // (column tile << 32) | (row in tile << 27) | index of the entry in the row
+            std::vector<uint32_t> ebeg(33);
+            for (int64_t rt = b * kBlk; rt < std::min(n_rt, (b + 1) * kBlk); ++rt) {
+                if (rt % stride != 0) continue;
+                key.clear();
+                const int rows = static_cast<int>(std::min<int64_t>(32, m - rt * 32));
+                bool fits = true;
+                for (int i = 0; i < rows; ++i) {
+                    const uint32_t r = sched[rt * 32 + i];
+                    const uint32_t e0 = A->rowPtr[r], e1 = A->rowPtr[r + 1];
+                    ebeg[i] = e0;
+                    if (e1 - e0 >= (1u << 27)) fits = false;
+                    for (uint32_t e = e0; e < e1 && fits; ++e) {
+                        const uint32_t c = A->col[e];
+                        const uint32_t cp = colpos.empty() ? c : colpos[c];
+                        key.push_back((static_cast<uint64_t>(cp >> 5) << 32) | (static_cast<uint64_t>(i) << 27) | (e - e0));
+                    }
+                }
+                if (!fits) continue;  // a row of >= 2^27 entries: left to the vector kernel
+                std::sort(key.begin(), key.end());
+                for (size_t z = 0; z < key.size();) {
+                    size_t z1 = z;
+                    while (z1 < key.size() && (key[z1] >> 32) == (key[z] >> 32)) ++z1;
+                    const int64_t cnt = static_cast<int64_t>(z1 - z);
+                    ++cells[b];
+                    if (cnt * 10 >= 1024) h0[b] += cnt;
+                    if (cnt * 4 >= 1024) h1[b] += cnt;
+                    if (cnt * 2 >= 1024) h2[b] += cnt;
+                    if (thr > 0 && cnt >= thr) {
+                        Found f{static_cast<uint32_t>(rt), static_cast<uint32_t>(key[z] >> 32), std::vector<float>(1024, 0.f)};
+                        uint8_t taken[32][32] = {};
+                        for (size_t y = z; y < z1; ++y) {
+                            const int i = static_cast<int>((key[y] >> 27) & 31);
+                            const uint32_t e = ebeg[i] + static_cast<uint32_t>(key[y] & ((1u << 27) - 1));
+                            const uint32_t c = A->col[e];
+                            const int j = static_cast<int>((colpos.empty() ? c : colpos[c]) & 31);
+                            if (taken[i][j]) continue;  // a duplicate (row, col) entry stays with the vector kernel
+                            taken[i][j] = 1;
+                            const int kk = j >> 1, lane = i + 32 * (j & 1);
+                            f.a[((kk >> 2) * 64 + lane) * 4 + (kk & 3)] = A->vals[e];
+                            in_tile[e - e_base] = 1;
+                            ++moved[b];
+                        }
+                        found[static_cast<size_t>(b)].push_back(std::move(f));
+                    }
+                    z = z1;
+                }
+            }
+        } catch (...) {
+            failed.store(1);
+        }
+    });
+    if (failed.load()) return FLEX_ERR_NOMEM;
+    for (int64_t b = 0; b < nblk; ++b) {
+        out.hist_nnz[0] += h0[b];
+        out.hist_nnz[1] += h1[b];
+        out.hist_nnz[2] += h2[b];
+        out.n_cells += cells[b];
+        out.nnz += moved[b];
+    }
+    if (thr == 0 || out.nnz == 0) return FLEX_OK;
+    // tiles in (row tile, column tile) order
+    const uint32_t n_cols = static_cast<uint32_t>(A->n);
+    try {
+        for (auto &blk : found)
+            for (Found &f : blk) {
+                out.a.insert(out.a.end(), f.a.begin(), f.a.end());
+                f.a = std::vector<float>();
+                for (uint32_t j = 0; j < 32; ++j) {
+                    uint32_t pos = f.ct * 32 + j;
+                    if (pos >= n_cols) pos = f.ct * 32;  // hangs over the last column: any valid row, its A entries are zero
+                    uint32_t c = colpos.empty() ? pos : sched[pos];
+                    if (col_map) c = static_cast<uint32_t>(col_map[c]);
+                    out.boff.push_back(off32 ? c * row_bytes32 : c);
+                }
+            }
+    } catch (const std::bad_alloc &) {
+        return FLEX_ERR_NOMEM;
+    }
+    // row-tile directory (second pass over the found list, which is already in (rt, ct) order)
+    out.rt_ptr.clear();
+    uint32_t t = 0, last_rt = 0xFFFFFFFFu;
+    for (auto &blk : found)
+        for (Found &f : blk) {
+            if (f.rt != last_rt) {
+                out.rt_ptr.push_back(t);
+                for (uint32_t i = 0; i < 32; ++i) {
+                    const int64_t sp = static_cast<int64_t>(f.rt) * 32 + i;
+                    uint32_t dst = 0xFFFFFFFFu;
+                    if (sp < m) {
+                        const uint32_t r = sched[sp];
+                        dst = dst_map ? static_cast<uint32_t>(dst_map[r]) : r - static_cast<uint32_t>(r0);
+                    }
+                    out.rt_rows.push_back(dst);
+                }
+                last_rt = f.rt;
+            }
+            ++t;
+        }
+    out.rt_ptr.push_back(t);
+    return FLEX_OK;
 }
 
 // Rows [r0,r1) of A.  col_map: B row read by column c (NULL = c).  dst_map: C row
@@ -215,6 +369,85 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     }
 
     lap("row schedule");
+    // position of a column's vertex in the schedule (what "near" means for a reordered square matrix); for a
+    // natural-order plan, a mapped plan or a row shard the column ids of A are positions already
+    std::vector<uint32_t> colpos;
+    if (order != FLEX_ORDER_NATURAL) {
+        colpos.resize(static_cast<size_t>(m));
+        for (int32_t i = 0; i < m; ++i) colpos[sched[i]] = static_cast<uint32_t>(i);
+    }
+
+    // ---- dense tiles -> MFMA kernel (FLEX_MFMA: 1 = route tiles of fill >= FLEX_MFMA_FILL %, 2 = never; default:
+    // route when a sampled look at every 16th row tile finds at least 2 % of the nonzeros in such tiles -- most
+    // graphs have none and then pay 1/16 of one pass).  With FLEX_PLAN_STATS the detector looks at every tile, so
+    // that its report (share of nonzeros in tiles of fill >= 0.10 / 0.25 / 0.50) is exact.
+    // Default threshold 60 %: measured on MI355X at k = 128 (tools/probe_mfma.py, 64-row diagonal blocks + 8 random
+    // entries per row, 200 K rows): routing blocks of fill 0.9 takes 297 -> 220 us, fill 0.6 228 -> 219 (break-even),
+    // fill 0.3 160 -> 217 (slower: a tile costs the same whatever its fill, and its 32 C rows are read and written
+    // once more), DESIGN.md 3.5.
+    const flex_csr *const A_in = A;
+    flex_csr A_f{};
+    std::vector<uint32_t> f_rowptr, f_col;
+    std::vector<float> f_vals;
+    DenseTiles tiles;
+    {
+        const long mode_mfma = env_long("FLEX_MFMA", 0);
+        const uint32_t fill_pct = static_cast<uint32_t>(std::clamp<long>(env_long("FLEX_MFMA_FILL", 60), 1, 100));
+        const uint32_t thr = (1024u * fill_pct + 99u) / 100u;
+        const bool report = (flags & FLEX_PLAN_STATS) != 0;
+        const int64_t nnz_in = static_cast<int64_t>(A->rowPtr[r1]) - A->rowPtr[r0];
+        bool route = mode_mfma == 1;
+        const uint32_t row_bytes32_t = static_cast<uint32_t>(p->ldb) * 4u;
+        std::vector<uint8_t> in_tile;
+        int rc_t = FLEX_OK;
+        if (mode_mfma != 1 && mode_mfma != 2 && m >= 2048 && nnz_in >= (1 << 16)) {  // the sampled look
+            DenseTiles probe;
+            rc_t = detect_dense_tiles(A, r0, m, sched, colpos, col_map, dst_map, p->off32, row_bytes32_t, 0, 16, in_tile, probe);
+            if (rc_t) return rc_t;
+            const int64_t share = fill_pct <= 10 ? probe.hist_nnz[0] : fill_pct <= 25 ? probe.hist_nnz[1] : probe.hist_nnz[2];  // >= 0.5 also screens for 0.6
+            route = share * 16 * 50 >= nnz_in;  // >= 2 % of the nonzeros, extrapolated from the sample
+        }
+        if (route || report) {
+            try {
+                if (route) in_tile.assign(static_cast<size_t>(nnz_in), 0);
+            } catch (const std::bad_alloc &) {
+                return FLEX_ERR_NOMEM;
+            }
+            rc_t = detect_dense_tiles(A, r0, m, sched, colpos, col_map, dst_map, p->off32, row_bytes32_t, route ? thr : 0, 1, in_tile, tiles);
+            if (rc_t) return rc_t;
+            p->tile_hist[0] = tiles.hist_nnz[0];
+            p->tile_hist[1] = tiles.hist_nnz[1];
+            p->tile_hist[2] = tiles.hist_nnz[2];
+            p->tile_cells = tiles.n_cells;
+            p->tile_hist_valid = true;
+        }
+        if (tiles.nnz > 0) {  // the vector kernel gets A minus the entries that moved into tiles (same rows, same ids)
+            try {
+                f_rowptr.assign(static_cast<size_t>(A->m) + 1, 0u);
+                f_col.resize(static_cast<size_t>(nnz_in - tiles.nnz));
+                f_vals.resize(static_cast<size_t>(nnz_in - tiles.nnz));
+            } catch (const std::bad_alloc &) {
+                return FLEX_ERR_NOMEM;
+            }
+            const uint32_t eb = A->rowPtr[r0];
+            uint32_t o = 0;
+            for (int32_t r = 0; r < A->m; ++r) {
+                f_rowptr[r] = o;
+                if (r < r0 || r >= r1) continue;
+                for (uint32_t e = A->rowPtr[r]; e < A->rowPtr[r + 1]; ++e)
+                    if (!in_tile[e - eb]) {
+                        f_col[o] = A->col[e];
+                        f_vals[o] = A->vals[e];
+                        ++o;
+                    }
+            }
+            f_rowptr[A->m] = o;
+            A_f = flex_csr{A->m, A->n, static_cast<int64_t>(o), f_rowptr.data(), f_col.data(), f_vals.data()};
+            A = &A_f;
+        }
+        lap("dense-tile detector");
+    }
+    (void)A_in;
     // chunk budget in records; rows longer than one budget are cut into pieces
     // chunk budget: short chunks keep the dispatcher's load balancing fine-grained on low-degree
     // graphs (flickr: best at ~96 records), long ones amortise the per-chunk descriptor chain on
@@ -259,14 +492,6 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     while ((2ull << pshift) * tile_bytes <= panel_bytes) ++pshift;  // P = 2^pshift rows of B per panel
     const uint32_t seg_min = static_cast<uint32_t>(env_long("FLEX_SEG_MIN", 4));
     constexpr uint32_t kFarPhase = 0xFFFFFFFEu;
-
-    // position of a column's vertex in the schedule (what "near" means for a reordered square matrix); for a
-    // natural-order plan, a mapped plan or a row shard the column ids of A are positions already
-    std::vector<uint32_t> colpos;
-    if (two_d && order != FLEX_ORDER_NATURAL) {
-        colpos.resize(static_cast<size_t>(m));
-        for (int32_t i = 0; i < m; ++i) colpos[sched[i]] = static_cast<uint32_t>(i);
-    }
 
     struct Piece {
         uint32_t spos;       // position of the piece's row in the schedule
@@ -544,6 +769,15 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     if ((rc = upload(&p->d_t_beg, t_beg, &p->device_bytes))) return rc;
     if ((rc = upload(&p->d_t_dst, t_dst, &p->device_bytes))) return rc;
     if ((rc = upload(&p->d_t_aux, t_aux, &p->device_bytes))) return rc;
+    p->n_tiles = static_cast<uint32_t>(tiles.boff.size() / 32);
+    p->n_row_tiles = tiles.rt_ptr.empty() ? 0u : static_cast<uint32_t>(tiles.rt_ptr.size() - 1);
+    p->tile_nnz = tiles.nnz;
+    if (p->n_tiles) {
+        if ((rc = upload(&p->d_tile_a, tiles.a, &p->device_bytes))) return rc;
+        if ((rc = upload(&p->d_tile_boff, tiles.boff, &p->device_bytes))) return rc;
+        if ((rc = upload(&p->d_rt_ptr, tiles.rt_ptr, &p->device_bytes))) return rc;
+        if ((rc = upload(&p->d_rt_rows, tiles.rt_rows, &p->device_bytes))) return rc;
+    }
     lap("upload records/tasks");
     // Chunk table in launch order: the kernel gives XCD x the x-th eighth of it.  The eighths are cut
     // by COST (records + per-row and per-chunk overhead), not by chunk count, and padded with empty
@@ -788,6 +1022,10 @@ int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc = launch_spmm(v, p->lanes_per_nz, p->off32, vec4, dB, dC, s);
     if (rc == FLEX_OK && !fused) rc = launch_fixup(p->d_partial, p->d_split, p->n_split, p->k, p->ldc, dC, s);
+    if (rc == FLEX_OK && p->n_tiles) {  // the dense tiles' share, added to the rows the kernels above have written
+        const TileView tv{p->d_tile_a, p->d_tile_boff, p->d_rt_ptr, p->d_rt_rows, p->n_row_tiles};
+        rc = launch_tiles(tv, p->off32, dB, dC, p->k, p->ldb, p->ldc, s);
+    }
     if (cur != p->device) (void)hipSetDevice(cur);
     return rc;
 }
@@ -820,6 +1058,8 @@ int flex_plan_get_info(const flex_plan *p, flex_plan_info *o) {
     o->plan_ms = p->plan_ms;
     o->n_slots = p->n_slots;
     o->two_d = p->two_d ? 1 : 0;
+    o->n_tiles = p->n_tiles;
+    o->tile_nnz = p->tile_nnz;
     o->panel_rows = p->two_d ? static_cast<int32_t>(p->panel_rows) : 0;
     return FLEX_OK;
 }

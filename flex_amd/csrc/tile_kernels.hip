@@ -1,0 +1,135 @@
+// tile_kernels.hip -- the dense-tile half of libflex_spmm.so: C[rows,:] += Atile[32x32] * B[cols,:] on the matrix cores.
+//
+// north_star: "MFMA only where RCM/Gorder reordering yields dense block-sparse tiles".  The reference only has a stub
+// there (flex_spmm.cu:1164-1168 prints "tensor core"); the orderings that would feed it are order_gorder.cu:35-143 and
+// DataLoader.cu:789-857.  Here the planner (plan.cpp, detect_dense_tiles) looks at the matrix in SCHEDULE coordinates
+// after the chosen ordering: a 32 x 32 tile (32 consecutive rows of the schedule x 32 consecutive column positions) whose
+// fill reaches the threshold leaves the record stream and is stored as a dense fp32 block; everything else stays with
+// the vector kernel.  This kernel then adds the dense part: one wave per row tile, all dense tiles of that row tile in
+// column order into 32 x 64 accumulators (v_mfma_f32_32x32x2_f32, two 32-column output tiles per wave), and ONE read-modify-
+// write of the 32 C rows at the end -- it runs after the vector kernel on the same stream, so the sum order is fixed
+// (vector part first, tiles in column order) and the result is reproducible.
+//
+// What the matrix core buys: the 32 gathered B rows of a tile are used by all 32 rows of A (the vector kernel gathers
+// a B row once per nonzero), and v_mfma_f32_32x32x2_f32 is an exact fp32 fmaf chain at the fp32 vector peak
+// (MI355X_MICROARCH.md: 64 FLOP/clk/SIMD); a tile does 1/fill times the useful flops, which is why only tiles above a
+// fill threshold are routed here.
+//   A operand: lane l holds A[row l&31][k = 2*kk + (l>>5)]      (stored by the planner in exactly this order)
+//   B operand: lane l holds B[colrow(2*kk + (l>>5))][c0 + (l&31)] (4-byte loads: 32 lanes = one 128-byte line of a B row)
+//   C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5)
+#include "internal.h"
+
+namespace flex {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kTileNT = 2;  // 32-column output tiles per wave: 64 columns of C per wave, grid.y = ceil(k / 64)
+
+// One wave = one row tile x 64 columns of C.  The loop is software-pipelined by hand: the sixteen B values of the next
+// k-group (four k-steps x kTileNT output tiles) and the next tile's A block and column offsets are in flight while the
+// MFMAs of the current group issue -- a wave otherwise spends six dependent memory round trips per tile (measured: 12 500
+// tiles took 220 us; the matrix cores need 21).
+template <bool OFF32>
+__global__ __launch_bounds__(256) void spmm_tile_kernel(TileView tv, const float *__restrict__ B, float *__restrict__ C, int k,
+                                                        int ldb, int ldc) {
+    constexpr int NT = kTileNT;
+    const int lane = threadIdx.x & 63;
+    const uint32_t rt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (rt >= tv.n_row_tiles) return;
+    const int half = lane >> 5, j = lane & 31;
+    const int n_base = blockIdx.y * (32 * NT);
+    const uint32_t t0 = tv.rt_ptr[rt], t1 = tv.rt_ptr[rt + 1];
+    const uint32_t row_l = tv.rt_rows[static_cast<uint64_t>(rt) * 32 + j];  // used by the epilogue only: issued early
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+    // columns this lane reads/writes; past k the address is clamped (a valid column of the same row) and the value zeroed
+    int col[NT];
+    bool col_ok[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        col_ok[nt] = n_base + nt * 32 + j < k;
+        col[nt] = col_ok[nt] ? n_base + nt * 32 + j : 0;
+    }
+    auto load_a = [&](uint32_t t, f32x4 (&a)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f32x4 *>(tv.a + (static_cast<uint64_t>(t) * 4 + q) * 256 + lane * 4);
+    };
+    auto load_b = [&](uint32_t boff_l, int q, float (&b)[4][NT]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t off = __shfl(boff_l, 2 * (4 * q + e) + half);
+            const float *brow = OFF32 ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + off)
+                                      : B + static_cast<uint64_t>(off) * ldb;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b[e][nt] = brow[col[nt]];
+        }
+    };
+    uint32_t boff_cur = tv.boff[static_cast<uint64_t>(t0) * 32 + j];
+    f32x4 a_cur[4];
+    load_a(t0, a_cur);
+    float bq[4][NT];
+    load_b(boff_cur, 0, bq);
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t tn = min(t + 1, t1 - 1);  // the last tile prefetches itself: harmless, keeps every load unconditional
+        const uint32_t boff_nxt = tv.boff[static_cast<uint64_t>(tn) * 32 + j];
+        f32x4 a_nxt[4];
+        load_a(tn, a_nxt);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float bn[4][NT];
+            if (q < 3) load_b(boff_cur, q + 1, bn);
+            else load_b(boff_nxt, 0, bn);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q][e], col_ok[nt] ? bq[e][nt] : 0.f, acc[nt], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bq[e][nt] = bn[e][nt];
+        }
+        boff_cur = boff_nxt;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
+    }
+    // C[rows of this row tile, :] += acc   (the vector kernel wrote those rows earlier on this stream).  All sixteen
+    // loads of an output tile go out before the first add: a load -> add -> store chain per element is sixty-four
+    // dependent round trips (the compiler cannot move a load of one C row above the store to another).
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        float *ptr[16];
+        float old[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const uint32_t dst = __shfl(row_l, (reg & 3) + 8 * (reg >> 2) + 4 * half);
+            // a row tile that hangs over the end of the schedule: point at a row that exists, never store
+            ptr[reg] = dst == 0xFFFFFFFFu ? nullptr : C + static_cast<uint64_t>(dst) * ldc + col[nt];
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) old[reg] = (ptr[reg] && col_ok[nt]) ? *ptr[reg] : 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            if (ptr[reg] && col_ok[nt]) *ptr[reg] = old[reg] + acc[nt][reg];
+    }
+}
+
+}  // namespace
+
+int launch_tiles(const TileView &tv, bool off32, const float *dB, float *dC, int k, int ldb, int ldc, hipStream_t s) {
+    if (tv.n_row_tiles == 0) return FLEX_OK;
+    const dim3 grid((tv.n_row_tiles + 3) / 4, (k + 32 * kTileNT - 1) / (32 * kTileNT)), block(256);
+    if (off32)
+        hipLaunchKernelGGL(spmm_tile_kernel<true>, grid, block, 0, s, tv, dB, dC, k, ldb, ldc);
+    else
+        hipLaunchKernelGGL(spmm_tile_kernel<false>, grid, block, 0, s, tv, dB, dC, k, ldb, ldc);
+    FLEX_HIP_TRY(hipGetLastError());
+    return FLEX_OK;
+}
+
+}  // namespace flex

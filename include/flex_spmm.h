@@ -144,6 +144,8 @@ typedef struct flex_plan_info {
     int64_t n_slots;      /* chunk-table entries launched: n_chunks + the empty entries that pad the XCD slices */
     int32_t two_d;        /* 1: rows are cut by column panel as well (each XCD slice runs phase by phase), else 0 */
     int32_t panel_rows;   /* two_d: B rows per column panel (a power of two), else 0 */
+    int64_t n_tiles;      /* dense 32x32 tiles of A routed to the MFMA kernel (0: the vector kernel does everything) */
+    int64_t tile_nnz;     /* nonzeros held by those tiles */
 } flex_plan_info;
 int flex_plan_get_info(const flex_plan *plan, flex_plan_info *out);
 
@@ -168,6 +170,13 @@ typedef struct flex_plan_stats {
     double split_nnz_pct;  /* share of nonzeros in rows cut into pieces (≙ share of work needing atomics) */
     double pad_pct;        /* 100 (records - nnz) / nnz */
     int64_t n_workgroups;
+    /* block-density detector (32x32 tiles in schedule coordinates; ≙ tools/block_density.py of round 1, now in the planner) */
+    double tile_nnz_pct_10; /* share of the nonzeros in tiles of fill >= 0.10 */
+    double tile_nnz_pct_25; /* ... >= 0.25 */
+    double tile_nnz_pct_50; /* ... >= 0.50 */
+    double tile_mean_fill;  /* nnz / (1024 * non-empty tiles) */
+    int64_t mfma_tiles;     /* tiles routed to the MFMA kernel */
+    double mfma_nnz_pct;    /* share of the nonzeros they hold */
 } flex_plan_stats;
 int flex_plan_get_stats(const flex_plan *plan, flex_plan_stats *out);
 

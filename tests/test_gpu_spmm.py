@@ -576,7 +576,7 @@ def test_seeded_fuzz_over_shapes_degrees_widths_schedules():
         cnt, max_err, me_nnz, _ = oracle.rescheck(gold, np.ascontiguousarray(C[:, :k]), a.rowPtr)
         assert cnt == 0, f"{tag}: {cnt} mismatches, max err {max_err:g} on a row of {me_nnz} nnz"
         st, info = p.stats(), p.info()
-        assert st["records"] >= a.nnz and info["n_slots"] >= info["n_chunks"] and info["nnz"] == a.nnz, tag
+        assert st["records"] + info["tile_nnz"] >= a.nnz and info["n_slots"] >= info["n_chunks"] and info["nnz"] == a.nnz, tag
         p.self_check()  # the device image of the plan is a partition of the work (≙ the tiler round-trip, mat.cu:905-940)
         p.destroy()
 
@@ -792,3 +792,100 @@ def test_two_d_reduction_is_stable_under_repetition(monkeypatch):
             assert torch.equal(C, ref), f"launch {it}: result changed"
     torch.cuda.synchronize()
     assert torch.equal(C, ref)
+
+
+def block_dense_graph(n, block, fill, noise_deg, seed):
+    """Block-diagonal-plus-noise matrix: dense diagonal blocks of `block` rows at `fill`, plus `noise_deg` random entries
+    per row -- the kind of input north_star's MFMA clause is about (what a good ordering makes of a clustered graph)."""
+    rng = np.random.default_rng(seed)
+    rows, cols = [], []
+    for b0 in range(0, n, block):
+        b1 = min(n, b0 + block)
+        mask = rng.random((b1 - b0, b1 - b0)) < fill
+        r, c = np.nonzero(mask)
+        rows.append(r + b0)
+        cols.append(c + b0)
+    rows.append(np.repeat(np.arange(n), noise_deg))
+    cols.append(rng.integers(0, n, size=n * noise_deg))
+    r, c = np.concatenate(rows), np.concatenate(cols)
+    key = np.unique(r.astype(np.int64) * n + c)
+    r, c = key // n, key % n
+    rp = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(r, minlength=n), out=rp[1:])
+    vals = rng.uniform(-1, 1, size=len(c)).astype(np.float32)
+    return flex_amd.HostCsr(rp.astype(np.uint32), c.astype(np.uint32), vals, n=n)
+
+
+@pytest.mark.parametrize("k", [128, 32, 100, 256, 7])
+def test_mfma_dense_tile_route_matches_oracle(monkeypatch, k):
+    """north_star: "MFMA only where ... reordering yields dense block-sparse tiles".  On a block-dense input the planner's
+    detector routes the dense 32x32 tiles to the v_mfma_f32_32x32x2_f32 kernel and the rest to the vector kernel; the sum
+    must pass resCheck against the oracle, be reproducible, and agree with the vector-only plan of the same matrix."""
+    a = block_dense_graph(12000, 64, 0.85, 6, seed=3)  # well above the default routing threshold (fill 0.6)
+    B = random_B(a.n, k, 17)
+    p = Plan(a, k, order=FLEX_ORDER_NATURAL | flex_amd.FLEX_PLAN_STATS)
+    info, st = p.info(), p.stats()
+    assert info["n_tiles"] > 300 and info["tile_nnz"] > 0.7 * a.nnz, info      # the route is taken
+    assert st["tile_nnz_pct_50"] > 70.0 and st["mfma_tiles"] == info["n_tiles"] and st["mfma_nnz_pct"] > 70.0
+    p.self_check()
+    C1 = run_plan(p, B)
+    assert_matches_oracle(a, B, C1)
+    assert np.array_equal(C1, run_plan(p, B))
+    monkeypatch.setenv("FLEX_MFMA", "2")
+    pv = Plan(a, k, order=FLEX_ORDER_NATURAL | flex_amd.FLEX_PLAN_STATS)
+    assert pv.info()["n_tiles"] == 0 and pv.stats()["tile_nnz_pct_50"] > 70.0   # the detector still reports, nothing is routed
+    assert oracle.rescheck(run_plan(pv, B), C1, a.rowPtr)[0] == 0
+
+
+def test_mfma_route_after_reordering_shards_strides_and_duplicates(monkeypatch):
+    """The detector works in SCHEDULE coordinates: a shuffled block-dense graph has no dense tile in natural order and
+    plenty after the community ordering; mapped plans, row shards, padded storage and duplicate entries go through."""
+    a0 = block_dense_graph(8000, 32, 0.8, 4, seed=5)
+    perm = np.random.default_rng(1).permutation(a0.m)  # relabel vertices at random
+    inv = np.argsort(perm)
+    rows = np.repeat(np.arange(a0.m), np.diff(a0.rowPtr.astype(np.int64)))
+    r2, c2 = perm[rows], perm[a0.col]
+    o = np.lexsort((c2, r2))
+    rp = np.zeros(a0.m + 1, dtype=np.int64)
+    np.cumsum(np.bincount(r2, minlength=a0.m), out=rp[1:])
+    a = flex_amd.HostCsr(rp.astype(np.uint32), c2[o].astype(np.uint32), a0.vals[o], n=a0.n)
+    del inv
+    k = 128
+    B = random_B(a.n, k, 4)
+    monkeypatch.setenv("FLEX_MFMA", "1")
+    monkeypatch.setenv("FLEX_MFMA_FILL", "25")  # communities do not start on tile boundaries: a block straddles tiles
+    nat = Plan(a, k, order=FLEX_ORDER_NATURAL)
+    clu = Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER)
+    assert nat.info()["tile_nnz"] < 0.05 * a.nnz < 0.3 * a.nnz < clu.info()["tile_nnz"]
+    gold, _ = assert_matches_oracle(a, B, run_plan(clu, B))
+    assert_matches_oracle(a, B, run_plan(nat, B))
+    # the reference's flow: permuted loader + vo_mp, then 3 row shards of it over padded storage
+    vo, ap = flex_amd.perm_csr(a, flex_amd.order_cluster(a))
+    pm = Plan(ap, k, vo_mp=vo)
+    assert pm.info()["n_tiles"] > 0
+    pm.self_check()
+    assert oracle.rescheck(gold, run_plan(pm, B), a.rowPtr)[0] == 0
+    ldb, ldc = k + 32, k + 4
+    Bs = np.full((a.n, ldb), np.nan, dtype=np.float32)
+    Bs[:, :k] = B
+    Bd = dev(Bs)
+    got = np.zeros_like(gold)
+    bounds = flex_amd.shard_rows(ap, k, 3)
+    for i in range(3):
+        ps = Plan(ap, k, rows=(bounds[i], bounds[i + 1]), col_map=vo, ldb=ldb, ldc=ldc)
+        assert ps.info()["n_tiles"] > 0
+        ps.self_check()
+        Cs = torch.full((bounds[i + 1] - bounds[i], ldc), 4.0, device="cuda")
+        ps.spmm(Bd.data_ptr(), Cs.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        Ch = Cs.cpu().numpy()
+        assert np.all(Ch[:, k:] == 4.0)
+        got[vo[bounds[i]:bounds[i + 1]]] = Ch[:, :k]
+    assert oracle.rescheck(gold, got, a.rowPtr)[0] == 0
+    # duplicates: the same (row, col) twice -- one copy rides in the tile, the other stays with the vector kernel
+    dup = flex_amd.HostCsr(np.arange(0, 64 * 65, 64, dtype=np.uint32)[:65], np.tile(np.repeat(np.arange(32, dtype=np.uint32), 2), 64),
+                           np.random.default_rng(2).uniform(-1, 1, 64 * 64).astype(np.float32), n=64)
+    Bdup = random_B(64, 32, 6)
+    pd = Plan(dup, 32)
+    assert pd.info()["n_tiles"] == 2 and pd.info()["tile_nnz"] == 2 * 1024
+    assert_matches_oracle(dup, Bdup, run_plan(pd, Bdup))
