@@ -14,11 +14,14 @@
 // In this engine an ordering is a SCHEDULE (which rows a wave / an XCD works on
 // next), never a data permutation: see plan.cpp.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <numeric>
 #include <stdexcept>
 #include <vector>
 
+#include "host_parallel.h"
 #include "internal.h"
 
 namespace flex {
@@ -30,22 +33,30 @@ struct Clusterer {
     const uint32_t *rowPtr, *col;
     std::vector<uint32_t> parent;                                 // union-find over communities
     std::vector<double> cdeg;                                     // community degree (sum of member degrees)
-    std::vector<std::vector<std::pair<uint32_t, float>>> adj;     // lazily compacted community adjacency
+    using Adj = std::vector<std::pair<uint32_t, float>>;
+    std::vector<Adj> adj;                                          // a community's adjacency as of its last compaction
+    std::vector<std::vector<Adj>> segs;                           // + the lists of the communities it has absorbed since (moved, not copied)
     std::vector<uint8_t> raw;                                     // adjacency still lives in the CSR
     std::vector<std::vector<uint32_t>> children;                  // merge forest
-    std::vector<float> acc;                                       // dense scratch: weight per neighbour root
-    std::vector<uint32_t> touched;
     double M = 0;                                                 // total degree (2m)
 
     Clusterer(int64_t n_, const uint32_t *rp, const uint32_t *c)
-        : n(n_), rowPtr(rp), col(c), parent(n_), cdeg(n_, 0.0), adj(n_), raw(n_, 1), children(n_), acc(n_, 0.f) {
+        : n(n_), rowPtr(rp), col(c), parent(n_), cdeg(n_, 0.0), adj(n_), segs(n_), raw(n_, 1), children(n_) {
         std::iota(parent.begin(), parent.end(), 0u);
-        for (int64_t u = 0; u < n; ++u) {
-            uint32_t d = 0;
-            for (uint32_t e = rowPtr[u]; e < rowPtr[u + 1]; ++e) d += (col[e] != u);
-            cdeg[u] = d;
-            M += d;
-        }
+        constexpr int64_t kBlk = 1 << 14;
+        const int64_t nblk = (n + kBlk - 1) / kBlk;
+        std::vector<double> part(static_cast<size_t>(nblk), 0.0);
+        parallel_chunks(nblk, [&](int64_t b) {
+            double m = 0;
+            for (int64_t u = b * kBlk; u < std::min(n, (b + 1) * kBlk); ++u) {
+                uint32_t d = 0;
+                for (uint32_t e = rowPtr[u]; e < rowPtr[u + 1]; ++e) d += (col[e] != u);
+                cdeg[u] = d;
+                m += d;
+            }
+            part[b] = m;
+        });
+        for (double m : part) M += m;  // block order: the same sum whatever the thread count
     }
 
     uint32_t find(uint32_t x) {
@@ -56,25 +67,32 @@ struct Clusterer {
         return x;
     }
 
-    // Rebuild u's adjacency keyed by CURRENT roots; returns the best merge target or u itself.
-    uint32_t compact_and_pick(uint32_t u) {
+    // Rebuild u's adjacency keyed by the roots of the state the round started from (`parent` is flat then: parent[v]
+    // IS v's root); returns the best merge target or u itself, and the weight of the edge bundle to it.
+    // Touches only adj[u] and the caller's scratch, so distinct communities can be examined concurrently.
+    uint32_t compact_and_pick(uint32_t u, std::vector<float> &acc, std::vector<uint32_t> &touched, float *w_best) {
         touched.clear();
         auto add = [&](uint32_t v, float w) {
-            const uint32_t r = find(v);
+            uint32_t r = v;  // read-only find: no merge happens while proposals are computed
+            while (parent[r] != r) r = parent[r];
             if (r == u) return;
             if (acc[r] == 0.f) touched.push_back(r);
-            acc[r] += w;
+            acc[r] += w;  // weights are edge counts: exact in fp32, so the order the neighbours are met in does not matter
         };
         if (raw[u]) {
             for (uint32_t e = rowPtr[u]; e < rowPtr[u + 1]; ++e) add(col[e], 1.f);
             raw[u] = 0;
         }
         for (const auto &vw : adj[u]) add(vw.first, vw.second);
+        for (const Adj &sg : segs[u])
+            for (const auto &vw : sg) add(vw.first, vw.second);
+        std::vector<Adj>().swap(segs[u]);
         auto &list = adj[u];
         list.clear();
         list.reserve(touched.size());
         uint32_t best = u;
         double best_gain = 0.0;
+        *w_best = 0.f;
         const double du_over_M = cdeg[u] / M;
         for (uint32_t r : touched) {
             const float w = acc[r];
@@ -85,39 +103,100 @@ struct Clusterer {
             if (gain > best_gain || (gain == best_gain && gain > 0.0 && r < best)) {
                 best_gain = gain;
                 best = r;
+                *w_best = w;
             }
         }
         return best;
     }
 
+    // Rounds.  Each round has three steps, and its result does not depend on the number of threads:
+    //  A (parallel)   every active community compacts its adjacency and PROPOSES the neighbour with the largest
+    //                 modularity gain, all from the state the round started with;
+    //  B (sequential, O(#active)) the proposals are applied lowest-degree community first: u joins the current root r
+    //                 of its choice unless u has absorbed something this round, or the gain -- re-priced with r's
+    //                 degree as it stands now, so that a popular community does not swallow a whole round of
+    //                 proposers -- is no longer positive (then u proposes again next round);
+    //  C (parallel over the absorbing communities) adjacency lists of the absorbed are appended to their new root's.
+    // (Round 1 of this project examined and merged one community at a time, each seeing every earlier merge: the
+    //  Amazon shape spent 8.4 s of its 9.3 s plan there, single-threaded.)
     void run(int max_rounds) {
         if (M <= 0) return;
-        std::vector<uint32_t> cur(static_cast<size_t>(n)), next;
+        const int nthr = host_threads();
+        std::vector<std::vector<float>> acc(static_cast<size_t>(nthr));
+        std::vector<std::vector<uint32_t>> touched(static_cast<size_t>(nthr));
+        std::vector<uint32_t> cur(static_cast<size_t>(n)), next, pick(static_cast<size_t>(n));
+        std::vector<float> pick_w(static_cast<size_t>(n));
         std::iota(cur.begin(), cur.end(), 0u);
         std::vector<uint32_t> stamp(static_cast<size_t>(n), 0u);
+        std::vector<std::pair<uint32_t, uint32_t>> moved;  // (new root, absorbed community) of the current batch, in the order decided
+        const int64_t env_batch = std::getenv("FLEX_CLUSTER_BATCH") ? std::atoll(std::getenv("FLEX_CLUSTER_BATCH")) : 4096;
+        const bool timing = std::getenv("FLEX_PLAN_TIMING") != nullptr;
+        double t_sort = 0, t_a = 0, t_b = 0, t_c = 0;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto secs = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
         for (int round = 1; round <= max_rounds && !cur.empty(); ++round) {
+            const auto ts0 = now();
             std::stable_sort(cur.begin(), cur.end(), [&](uint32_t a, uint32_t b) { return cdeg[a] < cdeg[b]; });
+            t_sort += secs(ts0, now());
             next.clear();
-            for (uint32_t u : cur) {
-                if (parent[u] != u) continue;        // merged earlier in this round
-                if (stamp[u] == static_cast<uint32_t>(round)) continue;  // just absorbed something: next round
-                const uint32_t v = compact_and_pick(u);
-                if (v == u) continue;
-                parent[u] = v;  // u joins v
-                cdeg[v] += cdeg[u];
-                children[v].push_back(u);
-                if (raw[v]) {  // materialise v's own edges before appending foreign ones
-                    for (uint32_t e = rowPtr[v]; e < rowPtr[v + 1]; ++e)
-                        if (col[e] != v) adj[v].emplace_back(col[e], 1.f);
-                    raw[v] = 0;
+            moved.clear();
+            const int64_t ncur = static_cast<int64_t>(cur.size());
+            const int64_t batch = std::max<int64_t>(256, env_batch);
+            for (int64_t b0 = 0; b0 < ncur; b0 += batch) {
+                const int64_t b1 = std::min(ncur, b0 + batch);
+                // A: proposals of this batch, from the state left by the batches before it
+                const auto ta0 = now();
+                constexpr int64_t kBlk = 64;
+                parallel_chunks_tid((b1 - b0 + kBlk - 1) / kBlk, [&](int64_t b, int tid) {
+                    if (acc[tid].empty()) acc[tid].assign(static_cast<size_t>(n), 0.f);
+                    for (int64_t i = b0 + b * kBlk; i < std::min(b1, b0 + (b + 1) * kBlk); ++i) {
+                        const uint32_t u = cur[i];
+                        if (parent[u] != u || stamp[u] == static_cast<uint32_t>(round)) {
+                            pick[u] = u;  // merged away or just absorbed something in an earlier batch: not its turn
+                            continue;
+                        }
+                        pick[u] = compact_and_pick(u, acc[tid], touched[tid], &pick_w[u]);
+                    }
+                });
+                // B
+                const auto tb0 = now();
+                t_a += secs(ta0, tb0);
+                for (int64_t i = b0; i < b1; ++i) {
+                    const uint32_t u = cur[i];
+                    const uint32_t v = pick[u];
+                    if (v == u) continue;                                     // no neighbour worth joining (or not its turn)
+                    if (stamp[u] == static_cast<uint32_t>(round)) continue;  // absorbed something inside this batch
+                    const uint32_t r = find(v);
+                    const bool gain_left = r != u && static_cast<double>(pick_w[u]) - cdeg[r] * cdeg[u] / M > 0.0;
+                    if (!gain_left) {  // its choice moved on or filled up: look again next round
+                        stamp[u] = static_cast<uint32_t>(round);
+                        next.push_back(u);
+                        continue;
+                    }
+                    parent[u] = r;  // u joins r
+                    cdeg[r] += cdeg[u];
+                    children[r].push_back(u);
+                    moved.emplace_back(r, u);
+                    if (stamp[r] != static_cast<uint32_t>(round)) {
+                        stamp[r] = static_cast<uint32_t>(round);
+                        next.push_back(r);
+                    }
                 }
-                adj[v].insert(adj[v].end(), adj[u].begin(), adj[u].end());
-                std::vector<std::pair<uint32_t, float>>().swap(adj[u]);
-                if (stamp[v] != static_cast<uint32_t>(round)) {
-                    stamp[v] = static_cast<uint32_t>(round);
-                    next.push_back(v);
+                // C: the absorbed communities' adjacency lists go to their new roots -- handed over, not copied (copying
+                // them was 12.8 s of the Amazon shape's 17 s): the root reads them when it is next compacted
+                const auto tc0 = now();
+                t_b += secs(tb0, tc0);
+                for (const auto &ru : moved) {
+                    auto &dst = segs[ru.first];
+                    dst.push_back(std::move(adj[ru.second]));
+                    for (Adj &sg : segs[ru.second]) dst.push_back(std::move(sg));
+                    Adj().swap(adj[ru.second]);
+                    std::vector<Adj>().swap(segs[ru.second]);
                 }
+                moved.clear();
+                t_c += secs(tc0, now());
             }
+            if (timing) std::fprintf(stderr, "cluster: round %d active %zu -> %zu  sort %.2f A %.2f B %.2f C %.2f s (cumulative)\n", round, cur.size(), next.size(), t_sort, t_a, t_b, t_c);
             cur.swap(next);
         }
     }

@@ -34,4 +34,22 @@ void parallel_chunks(int64_t nchunks, F &&fn) {
     for (auto &t : th) t.join();
 }
 
+// the same, fn(chunk, worker) with worker in [0, host_threads()): for per-worker scratch
+template <typename F>
+void parallel_chunks_tid(int64_t nchunks, F &&fn) {
+    const int nt = static_cast<int>(std::min<int64_t>(host_threads(), nchunks));
+    if (nt <= 1) {
+        for (int64_t c = 0; c < nchunks; ++c) fn(c, 0);
+        return;
+    }
+    std::atomic<int64_t> next{0};
+    std::vector<std::thread> th;
+    th.reserve(nt);
+    for (int t = 0; t < nt; ++t)
+        th.emplace_back([&, t] {
+            for (int64_t c; (c = next.fetch_add(1)) < nchunks;) fn(c, t);
+        });
+    for (auto &t : th) t.join();
+}
+
 }  // namespace flex
