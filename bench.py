@@ -51,6 +51,12 @@ def parse():
     ap.add_argument("--no-copy-probe", action="store_true", help="skip the streaming read / copy probe that measures achievable HBM GB/s")
     ap.add_argument("--no-vendor", action="store_true", help="skip the hipSPARSE side-by-side (N=1 only)")
     ap.add_argument("--check", action="store_true", help="verify rank 0's shard against the oracle (small workloads)")
+    ap.add_argument("--shrink", type=int, default=1, help="rehearsals only: the preset with n and nnz divided by this (same generator and code path)")
+    ap.add_argument("--init-timeout", type=float, default=600.0, help="seconds to wait for the other ranks at start-up before failing (non-zero exit)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU, nothing measured: every rank runs the host side of the N-GPU path (same graph, same re-ordering, "
+                         "flex_shard_rows, the B broadcast over gloo) and rank 0 prints the JSON line with zeros for the times -- "
+                         "what the world_size-8 CPU test drives")
     return ap.parse_args()
 
 
@@ -66,23 +72,33 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if not torch.cuda.is_available():
+    if args.dry_run:
+        args.backend = "gloo"
+        args.no_cpu_baseline = args.no_copy_probe = args.no_vendor = True
+    elif not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: there is no CPU fallback for the measured path")
     if "FLEX_BENCH_DEVICE" in os.environ:  # rehearsal only: every rank on one card
         local_rank = int(os.environ["FLEX_BENCH_DEVICE"])
-    torch.cuda.set_device(local_rank)
+    if not args.dry_run:
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        tmo = datetime.timedelta(seconds=args.init_timeout)
         try:
             if args.backend == "nccl":
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=tmo)
                 probe = torch.ones(1, device=torch.device("cuda", local_rank))
                 dist.all_reduce(probe)  # the communicator is created lazily: force RCCL up before any planning work
                 torch.cuda.synchronize()
                 if int(probe.item()) != world:
                     raise RuntimeError(f"all_reduce over {world} ranks returned {probe.item()}")
             else:
-                dist.init_process_group("gloo", rank=rank, world_size=world)
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
+                probe = torch.ones(1)
+                dist.all_reduce(probe)
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"all_reduce over {world} ranks returned {probe.item()}")
         except Exception as e:  # noqa: BLE001 -- a rank that cannot reach the others must fail the job, not hang it
             print(f"bench.py: rank {rank}: {args.backend} initialisation failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
             os._exit(3)  # no destructor may block on a half-made communicator; the launcher tears the other ranks down
@@ -99,14 +115,25 @@ def main():
              flex_amd.csr_load_bin(args.graph) if ext == ".bin" else flex_amd.csv_load(args.graph))
         args.workload = os.path.splitext(os.path.basename(args.graph))[0] + " (file)"
     else:
-        a = flex_amd.synth_graph(args.workload, scale=scale, shuffle=bool(args.shuffle))
+        if args.shrink > 1:  # same generator, same structure parameters, n and nnz divided (rehearsals)
+            sp = flex_amd.synth_preset(args.workload, scale)
+            n_s = max(64, sp.n // args.shrink)
+            nnz_s = max(n_s, sp.nnz // args.shrink)
+            nnz_s -= (nnz_s - n_s) & 1 if not sp.directed else 0
+            a = flex_amd.synth_graph(n=n_s, nnz=nnz_s, alpha=sp.alpha, community=sp.community, p_in=sp.p_in, p_near=sp.p_near,
+                                     near_window=sp.near_window, shuffle=bool(args.shuffle), gcn_norm=bool(sp.gcn_norm),
+                                     directed=bool(sp.directed), seed=sp.seed)
+            args.workload += f"/{args.shrink}"
+        else:
+            a = flex_amd.synth_graph(args.workload, scale=scale, shuffle=bool(args.shuffle))
     t_gen = time.perf_counter() - t_gen
 
     # ---- plan: RCM is a schedule (N=1) or an explicit permutation followed by row sharding (N>1)
     t_plan = time.perf_counter()
     order = {"cluster": flex_amd.FLEX_ORDER_CLUSTER, "rcm": flex_amd.FLEX_ORDER_RCM,
              "natural": flex_amd.FLEX_ORDER_NATURAL}[args.order]
-    if world == 1:
+    want_stats = False
+    if world == 1 and not args.dry_run:
         want_stats = a.nnz <= 50_000_000  # one extra pass over the records: skipped on amazon-size inputs
         plan = flex_amd.Plan(a, k, device=local_rank, order=order | (flex_amd.FLEX_PLAN_STATS if want_stats else 0)
                              | (flex_amd.FLEX_PLAN_AUTOTUNE if args.autotune else 0))
@@ -114,12 +141,14 @@ def main():
         shard = None
     else:
         shard = flex_amd.make_shard(a, k, rank, world, order=args.order)
-        plan = shard.plan(k, local_rank)
+        plan = None if args.dry_run else shard.plan(k, local_rank)
         shard_nnz, shard_rows = shard.nnz, shard.r1 - shard.r0
     t_plan = time.perf_counter() - t_plan
-    info = plan.info()
+    info = plan.info() if plan is not None else {"n_chunks": 0, "n_tasks": 0, "n_split_rows": 0, "lanes_per_nz": 0, "two_d": 0, "n_tiles": 0}
 
     # ---- B: generated on rank 0, broadcast once over RCCL/xGMI (untimed, reported)
+    if args.dry_run:
+        return dry_run_tail(args, a, k, rank, world, shard, t_gen, t_plan)
     dev = torch.device("cuda", local_rank)
     if rank == 0:
         g = torch.Generator(device=dev)
@@ -208,7 +237,8 @@ def main():
                             + f"{args.order} schedule" + (f", rows sharded over {world} GPUs, B broadcast once" if world > 1 else ""),
                 "n": a.n, "nnz": a.nnz, "k": k, "order": args.order, "parallelism": f"row-shard x{world}",
                 "plan": {"chunks": info["n_chunks"], "tasks": info["n_tasks"], "split_rows": info["n_split_rows"],
-                         "lanes_per_nz": info["lanes_per_nz"], "plan_s": round(t_plan, 3), "gen_s": round(t_gen, 3)},
+                         "lanes_per_nz": info["lanes_per_nz"], "two_d": info["two_d"], "mfma_tiles": info["n_tiles"],
+                         "plan_s": round(t_plan, 3), "gen_s": round(t_gen, 3)},
                 "b_bcast_ms": round(bcast_ms, 3),
                 # ≙ the README's "tPre/tElap" column (README.md:34-42): preprocessing (ordering + planning + upload) over
                 # one execution of the kernel
@@ -258,6 +288,46 @@ def main():
         if world == 1 and not args.no_cpu_baseline:  # a reported baseline, timed at N=1 only
             out["cpu_baseline"] = side("cpu_baseline", lambda: cpu_baseline(a, k, B))
         print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def dry_run_tail(args, a, k, rank, world, shard, t_gen, t_plan):
+    """--dry-run: the host side of the N-rank path without a GPU -- B by one broadcast, every rank's shard reported to
+    rank 0, which checks that the shards tile the rows and prints the JSON line (times zero: nothing was measured)."""
+    import torch
+    import torch.distributed as dist
+    B = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, (a.n, k)).astype(np.float32)) if rank == 0 \
+        else torch.zeros((a.n, k), dtype=torch.float32)
+    t0 = time.perf_counter()
+    if world > 1:
+        import flex_amd
+        flex_amd.broadcast_dense(B, src=0, method=args.bcast)
+    bcast_ms = (time.perf_counter() - t0) * 1e3
+    mine = (shard.r0, shard.r1, shard.nnz, float(B.double().sum()), [int(x) for x in shard.bounds])
+    allr = [None] * world
+    if world > 1:
+        dist.all_gather_object(allr, mine)
+    else:
+        allr = [mine]
+    if rank == 0:
+        ok = (all(r[4] == allr[0][4] for r in allr) and all(abs(r[3] - allr[0][3]) < 1e-6 for r in allr)
+              and [r[0] for r in allr] == allr[0][4][:-1] and [r[1] for r in allr] == allr[0][4][1:]
+              and sum(r[2] for r in allr) == a.nnz)
+        nnzs = [r[2] for r in allr]
+        out = {"metric": "SpMM GFLOPS (2*nnz*k/t)", "value": 0.0, "unit": "GFLOPS", "n_gpus": world, "steps": 0, "warmup": 0,
+               "ms_per_step": 0.0, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic", "dry_run": True, "shards_consistent": bool(ok),
+               "config": {"workload": f"{args.workload}-shape synthetic graph (n={a.n}, nnz={a.nnz}), k={k}, fp32, {args.order} schedule, "
+                                      f"rows sharded over {world} ranks, B broadcast once (DRY RUN: no GPU, nothing measured)",
+                          "n": a.n, "nnz": a.nnz, "k": k, "order": args.order, "parallelism": f"row-shard x{world}",
+                          "plan": {"plan_s": round(t_plan, 3), "gen_s": round(t_gen, 3)}, "b_bcast_ms": round(bcast_ms, 3),
+                          "per_rank_ms": [0.0] * world, "per_rank_nnz": nnzs, "per_rank_rows": [r[1] - r[0] for r in allr],
+                          "shard_nnz_imbalance_pct": round(100.0 * max(nnzs) * world / max(sum(nnzs), 1) - 100.0, 2)}}
+        print(json.dumps(out), flush=True)
+        if not ok:
+            raise SystemExit("bench --dry-run: the ranks disagree about the shards or about B")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

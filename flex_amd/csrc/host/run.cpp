@@ -217,9 +217,18 @@ void run(DataLoader &input_vo) {
     if (o.gpus > 0) {  // row-sharded over several GPUs (new; the reference is single-GPU, flex.cu:4137)
         flex_mg *mg = nullptr;
         const flex_csr a = input_vo.csr_view();
-        FLEX_CHECK(flex_mg_create(&mg, &a, static_cast<int>(input_vo.dim), o.gpus, nullptr, FLEX_ORDER_CLUSTER));
+        // a failure here (no such device, RCCL cannot bring the communicator up) must end the run with a non-zero exit
+        // and say which layer failed: FLEX_CHECK throws, main() turns that into exit code 1; the RCCL result is printed first
+        auto mg_check = [&](int st, const char *what) {
+            if (st == FLEX_OK) return;
+            std::printf("flex --gpus %d: %s failed: %s (rccl result %d, hip error %d: %s)\n", o.gpus, what, flex_strerror(st), flex_mg_last_rccl(),
+                        flex_last_hip_error(), flex_last_hip_error_string());
+            std::fflush(stdout);
+            FLEX_CHECK(st);
+        };
+        mg_check(flex_mg_create(&mg, &a, static_cast<int>(input_vo.dim), o.gpus, nullptr, FLEX_ORDER_CLUSTER), "flex_mg_create");
         double bcast_ms = 0, us = 0;
-        FLEX_CHECK(flex_mg_set_B(mg, input_vo.cpuX.data(), &bcast_ms));
+        mg_check(flex_mg_set_B(mg, input_vo.cpuX.data(), &bcast_ms), "flex_mg_set_B (RCCL broadcast)");
         FLEX_CHECK(flex_mg_time(mg, o.warmup, o.iters, &us));
         FLEX_CHECK(flex_mg_get_C(mg, h_res.get()));
         std::vector<int64_t> bounds(o.gpus + 1), snnz(o.gpus);

@@ -30,6 +30,7 @@ struct PlanView {
     int32_t ldb, ldc;        // floats between consecutive rows of B and of C (>= k; == k for dense operands)
     uint32_t xcd_remap;      // 1: remap workgroup ids so each XCD walks one contiguous slice of the schedule
     uint32_t lds_extra;      // bytes of unused dynamic LDS per workgroup (occupancy throttle, tuning only)
+    uint32_t rec_nt;         // 1: the record stream is read with non-temporal loads
     uint64_t *trace;         // diagnostic builds (-DFLEX_TRACE) only: 6 words per wave; nullptr otherwise
 };
 
@@ -61,7 +62,7 @@ void note_hip_error(hipError_t e);
 
 // kernel launchers (spmm_kernels.hip)
 int launch_spmm(const PlanView &v, int lanes_per_nz, bool off32, bool vec4, const float *dB, float *dC,
-                hipStream_t s);
+                hipStream_t s, int unroll = 0);
 int launch_fixup(const float *partial, const SplitRow *rows, uint32_t n_rows, int k, int ldc, float *dC,
                  hipStream_t s);
 int kernel_attributes(int lanes_per_nz, bool off32, bool vec4, hipFuncAttributes *attr, int *waves_per_cu);

@@ -63,6 +63,8 @@ struct flex_plan {
     bool off32 = false;
     bool xcd_remap = true;
     unsigned lds_extra = 0;
+    bool rec_nt = false;
+    int unroll = 0;
     uint64_t *trace = nullptr;
     unsigned order = 0;
     uint2 *d_rec = nullptr;
@@ -378,8 +380,8 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     }
 
     // ---- dense tiles -> MFMA kernel (FLEX_MFMA: 1 = route tiles of fill >= FLEX_MFMA_FILL %, 2 = never; default:
-    // route when a sampled look at every 16th row tile finds at least 2 % of the nonzeros in such tiles -- most
-    // graphs have none and then pay 1/16 of one pass).  With FLEX_PLAN_STATS the detector looks at every tile, so
+    // route when a sampled look at every 64th row tile finds at least 2 % of the nonzeros in such tiles -- most
+    // graphs have none and then pay 1/64 of one pass).  With FLEX_PLAN_STATS the detector looks at every tile, so
     // that its report (share of nonzeros in tiles of fill >= 0.10 / 0.25 / 0.50) is exact.
     // Default threshold 60 %: measured on MI355X at k = 128 (tools/probe_mfma.py, 64-row diagonal blocks + 8 random
     // entries per row, 200 K rows): routing blocks of fill 0.9 takes 297 -> 220 us, fill 0.6 228 -> 219 (break-even),
@@ -402,10 +404,10 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
         int rc_t = FLEX_OK;
         if (mode_mfma != 1 && mode_mfma != 2 && m >= 2048 && nnz_in >= (1 << 16)) {  // the sampled look
             DenseTiles probe;
-            rc_t = detect_dense_tiles(A, r0, m, sched, colpos, col_map, dst_map, p->off32, row_bytes32_t, 0, 16, in_tile, probe);
+            rc_t = detect_dense_tiles(A, r0, m, sched, colpos, col_map, dst_map, p->off32, row_bytes32_t, 0, 64, in_tile, probe);
             if (rc_t) return rc_t;
             const int64_t share = fill_pct <= 10 ? probe.hist_nnz[0] : fill_pct <= 25 ? probe.hist_nnz[1] : probe.hist_nnz[2];  // >= 0.5 also screens for 0.6
-            route = share * 16 * 50 >= nnz_in;  // >= 2 % of the nonzeros, extrapolated from the sample
+            route = share * 64 * 50 >= nnz_in;  // >= 2 % of the nonzeros, extrapolated from the sample
         }
         if (route || report) {
             try {
@@ -463,6 +465,14 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     const uint32_t row_cost = static_cast<uint32_t>(env_long("FLEX_ROW_COST", 16));
     p->xcd_remap = env_long("FLEX_XCD_REMAP", 1) != 2;  // 2 = off (tuning experiments only)
     p->lds_extra = static_cast<unsigned>(env_long("FLEX_LDS_EXTRA", 1)) & ~15u;  // default 0 (1 -> 0)
+    // the record stream is read once per column tile: non-temporal loads keep it from displacing B rows in the L2s and
+    // the Infinity Cache.  Measured (tools/probe_2d.py): amazon shape 9.48 -> 9.00 ms, reddit 697 -> 688 us;
+    // on by default once the stream is large against the caches (>= 32 MB), FLEX_REC_NT = 1 / 2 forces it on / off
+    {
+        const long nt_env = env_long("FLEX_REC_NT", 0);
+        p->rec_nt = nt_env == 1 || (nt_env != 2 && static_cast<uint64_t>(A->rowPtr[r1] - A->rowPtr[r0]) * 8u >= (32u << 20));
+    }
+    p->unroll = static_cast<int>(env_long("FLEX_U", 0));
     const uint32_t S = 64u / static_cast<uint32_t>(G);      // records per step: rows are padded to it
     // Rows longer than one budget are cut into pieces of one budget, each a chunk of its own that
     // writes a k-wide partial sum: one wave keeps only U gathers in flight, so a long row is much
@@ -1018,9 +1028,9 @@ int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream) {
     const bool fused = vec4 && p->fused_fixup;  // the generic kernel always leaves the sum to spmm_fixup_kernel
     PlanView v{p->d_rec, p->d_t_beg, p->d_t_dst, p->d_t_aux, p->d_chunk, p->d_partial, p->d_split, p->d_split_cnt,
                fused ? 1u : 0u, p->n_slots, p->k, p->ldb, p->ldc,
-               p->xcd_remap ? 1u : 0u, p->lds_extra, p->trace};
+               p->xcd_remap ? 1u : 0u, p->lds_extra, p->rec_nt ? 1u : 0u, p->trace};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    int rc = launch_spmm(v, p->lanes_per_nz, p->off32, vec4, dB, dC, s);
+    int rc = launch_spmm(v, p->lanes_per_nz, p->off32, vec4, dB, dC, s, p->unroll);
     if (rc == FLEX_OK && !fused) rc = launch_fixup(p->d_partial, p->d_split, p->n_split, p->k, p->ldc, dC, s);
     if (rc == FLEX_OK && p->n_tiles) {  // the dense tiles' share, added to the rows the kernels above have written
         const TileView tv{p->d_tile_a, p->d_tile_boff, p->d_rt_ptr, p->d_rt_rows, p->n_row_tiles};

@@ -227,16 +227,33 @@ constexpr int kWindowRecs = 256;  // records staged per wave and window (2 KiB o
 // inside its branch, so (a) a long window has its four loads in flight together instead of four round
 // trips and (b) no pending load survives into the gather loop, where the compiler would otherwise put an
 // s_waitcnt vmcnt(0) at the loop head.
-__device__ __forceinline__ void stage_window(uint2 *my_lds, const uint2 *__restrict__ rec, uint32_t wz, uint32_t wn, int lane) {
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ uint2 load_rec(const uint2 *ptr) {
+    if constexpr (NT) {  // records are read once per column tile: keep them out of the way of the B rows in L2 / Infinity Cache
+        const v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(ptr));
+        return make_uint2(v.x, v.y);
+    } else {
+        return *ptr;
+    }
+}
+
+template <bool NT>
+__device__ __forceinline__ void stage_window_t(uint2 *my_lds, const uint2 *__restrict__ rec, uint32_t wz, uint32_t wn, int lane) {
     if (wn <= 64) {
-        my_lds[lane] = rec[wz + min(static_cast<uint32_t>(lane), wn - 1)];
+        my_lds[lane] = load_rec<NT>(rec + wz + min(static_cast<uint32_t>(lane), wn - 1));
     } else {
         uint2 r[kWindowRecs / 64];
 #pragma unroll
-        for (int i = 0; i < kWindowRecs / 64; ++i) r[i] = rec[wz + min(static_cast<uint32_t>(i * 64 + lane), wn - 1)];
+        for (int i = 0; i < kWindowRecs / 64; ++i) r[i] = load_rec<NT>(rec + wz + min(static_cast<uint32_t>(i * 64 + lane), wn - 1));
 #pragma unroll
         for (int i = 0; i < kWindowRecs / 64; ++i) my_lds[i * 64 + lane] = r[i];
     }
+}
+
+__device__ __forceinline__ void stage_window(uint2 *my_lds, const uint2 *__restrict__ rec, uint32_t wz, uint32_t wn, int lane, bool nt) {
+    if (nt) stage_window_t<true>(my_lds, rec, wz, wn, lane);  // wave-uniform
+    else stage_window_t<false>(my_lds, rec, wz, wn, lane);
 }
 
 // All the work of one chunk once its header {first task, #tasks, first record, end record} and its
@@ -308,7 +325,7 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
     for (uint32_t wz = zb; wz < ze; wz += kWindowRecs) {
         const uint32_t wn = min(static_cast<uint32_t>(kWindowRecs), ze - wz);
         // stage this window's records: coalesced 512-B loads, one ds_write_b64 per lane and load
-        stage_window(my_lds, rec, wz, wn, lane);
+        stage_window(my_lds, rec, wz, wn, lane, p.rec_nt != 0);
         FLEX_STAMP(1);  // records -> LDS
 #ifdef FLEX_ABL_STAGEONLY  // timing-only ablation: header, descriptors and records fetched, then leave
         if (p.k > 0) {
@@ -605,7 +622,7 @@ int launch_v4_off(const PlanView &v, bool off32, const float *dB, float *dC, hip
 }  // namespace
 
 int launch_spmm(const PlanView &v, int lanes_per_nz, bool off32, bool vec4, const float *dB, float *dC,
-                hipStream_t s) {
+                hipStream_t s, int unroll) {
     if (v.n_chunks == 0) return FLEX_OK;
     if (!vec4) {
         uint32_t nblk = (v.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -617,6 +634,13 @@ int launch_spmm(const PlanView &v, int lanes_per_nz, bool off32, bool vec4, cons
             hipLaunchKernelGGL((spmm_generic_kernel<false>), dim3(nblk, ktiles), dim3(256), 0, s, v, dB, dC);
         FLEX_HIP_TRY(hipGetLastError());
         return FLEX_OK;
+    }
+    if (unroll == 8) {  // tuning experiments (FLEX_U=8): twice the gathers in flight per wave on the narrow tiles
+        switch (lanes_per_nz) {
+            case 8: return launch_v4_off<8, 8>(v, off32, dB, dC, s);
+            case 16: return launch_v4_off<16, 8>(v, off32, dB, dC, s);
+            default: break;
+        }
     }
     switch (lanes_per_nz) {  // U: 4 KiB in flight per wave on the narrow tiles, 8 KiB on the wide ones (U=8 on G<=16 measured the same)
         case 8: return launch_v4_off<8, 4>(v, off32, dB, dC, s);

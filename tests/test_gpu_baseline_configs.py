@@ -140,3 +140,47 @@ def test_suitesparse_standins_engine_and_hipsparse_vs_oracle(name, k):
         p.self_check()
         assert_matches_oracle(a, B, run_plan(p, Bd), nthreads=CORES)
     assert_matches_oracle(a, B, vendor_spmm(a, k, B), nthreads=CORES)
+
+
+def test_four_rank_rehearsal_of_the_strong_scaling_bench_on_one_card():
+    """The N > 1 code path of bench.py (row shards after the community re-ordering, col_map = vo_mp, B broadcast, per-rank
+    timing gathered on rank 0) with four `gloo` ranks sharing this box's one GPU -- a rehearsal of the driver's 8-GPU
+    launch, not a measurement: rank 0's shard is checked against the oracle, the JSON line carries the per-rank fields."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 4
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   FLEX_BENCH_DEVICE="0", FLEX_HOST_THREADS="4", OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--backend", "gloo",
+                                       "--workload", "amazon", "--shrink", "32", "--steps", "5", "--warmup", "2", "--check"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    lines = [ln for so, _ in outs for ln in so.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    c = j["config"]
+    assert j["n_gpus"] == 4 and j["scaling"] == "strong" and j["check"]["mismatches"] == 0 and j["value"] > 0
+    assert len(c["per_rank_ms"]) == 4 and min(c["per_rank_ms"]) > 0 and sum(c["per_rank_nnz"]) == c["nnz"]
+    assert c["shard_nnz_imbalance_pct"] < 25.0 and c["b_bcast_ms"] > 0
+
+
+def test_cxx_multi_gpu_driver_fails_loudly_without_enough_devices():
+    """`flex ... --gpus N` with more GPUs than the box has: the driver must say which layer failed and exit non-zero."""
+    import subprocess
+    n = torch.cuda.device_count()
+    exe = os.path.join(os.path.dirname(flex_amd.lib_path()), "flex")
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pubmed.csv")
+    out = subprocess.run([exe, golden, "32", "--no-vendor", "--gpus", str(n + 2)], capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert "flex_mg_create failed" in out.stdout and "rccl result" in out.stdout, out.stdout[-1500:] + out.stderr[-500:]

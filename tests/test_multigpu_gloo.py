@@ -146,3 +146,46 @@ def test_three_rank_broadcast_of_the_dense_operand(tmp_path):
         log, _ = p.communicate(timeout=300)
         assert p.returncode == 0, log
     assert open(out).read() == "ok"
+
+
+def _launch_bench(world, extra, timeout=600, env_extra=None, ranks=None):
+    port = _free_port()
+    procs = []
+    for r in (range(world) if ranks is None else ranks):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", FLEX_HOST_THREADS="2", **(env_extra or {}))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + extra, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    return procs, outs
+
+
+def test_eight_rank_dry_run_of_the_bench_on_a_scaled_down_amazon():
+    """bench.py --dry-run: the N = 8 strong-scaling path the driver launches (same preset scaled down, same re-ordering,
+    same flex_shard_rows, one broadcast of B) with 8 `gloo` ranks and no GPU: every rank must derive the same shards,
+    receive the same B, and rank 0's JSON line must carry the per-rank fields."""
+    import json
+    pytest.importorskip("torch")
+    procs, outs = _launch_bench(8, ["--dry-run", "--workload", "amazon", "--shrink", "512", "--scaling", "strong", "--bcast", "scatter_allgather"])
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    lines = [ln for so, _ in outs for ln in so.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["scaling"] == "strong" and j["dry_run"] and j["shards_consistent"]
+    c = j["config"]
+    assert len(c["per_rank_ms"]) == 8 and len(c["per_rank_nnz"]) == 8 and sum(c["per_rank_nnz"]) == c["nnz"]
+    assert sum(c["per_rank_rows"]) == c["n"] and min(c["per_rank_rows"]) > 0
+    assert c["shard_nnz_imbalance_pct"] < 25.0 and "amazon/512" in c["workload"]
+
+
+def test_a_rank_that_cannot_reach_the_others_exits_nonzero_instead_of_hanging():
+    """Start-up failure path: world size 2 but only rank 1 is launched; with --init-timeout the rendezvous gives up, the rank
+    prints which layer failed and exits with a non-zero status (never a hang, never a silent fallback)."""
+    pytest.importorskip("torch")
+    import time
+    t0 = time.time()
+    procs, outs = _launch_bench(2, ["--dry-run", "--workload", "pubmed", "--init-timeout", "5"], timeout=120, ranks=[1])
+    assert procs[0].returncode not in (0, None), outs[0]
+    assert "initialisation failed" in outs[0][1] or "imed out" in outs[0][1] or "onnect" in outs[0][1], outs[0][1][-1500:]
+    assert time.time() - t0 < 100
