@@ -273,6 +273,13 @@ def main():
             except Exception as e:  # noqa: BLE001
                 return {"error": f"{name}: {type(e).__name__}: {e}"}
 
+        if world == 1:
+            # ≙ the reference's per-SM "Imb" column (flex.cu:5087-5126): one stamped launch AFTER the timed region
+            im = side("imbalance", lambda: plan.measure_imbalance(bp, cp, stream))
+            out["config"]["plan"]["imbalance"] = im if "error" in im else {
+                "cu_busy_imb_pct": round(im["cu_busy_imb_pct"], 2), "cu_end_spread_pct": round(im["cu_end_spread_pct"], 2),
+                "xcd_busy_imb_pct": round(im["xcd_busy_imb_pct"], 2), "xcd_end_spread_pct": round(im["xcd_end_spread_pct"], 2),
+                "cus_seen": im["cus_seen"], "waves": im["waves"], "wave_us_mean": round(im["wave_us_mean"], 2), "wave_us_max": round(im["wave_us_max"], 2)}
         if world == 1 and not args.no_copy_probe:
             # achievable HBM bandwidth on this box, measured by the library's own streaming kernels
             pr = side("hbm_probe", lambda: flex_amd.hbm_probe(local_rank, mib=2048, reps=10))

@@ -76,6 +76,12 @@ class _KernelInfo(C.Structure):  # flex_kernel_info
                 ("threads_per_block", C.c_int32), ("waves_per_cu", C.c_int32)]
 
 
+class _Imbalance(C.Structure):  # flex_imbalance
+    _fields_ = [("waves", C.c_int64), ("cus_seen", C.c_int32), ("xcds_seen", C.c_int32), ("span_us", C.c_double),
+                ("cu_busy_imb_pct", C.c_double), ("cu_end_spread_pct", C.c_double), ("xcd_busy_imb_pct", C.c_double),
+                ("xcd_end_spread_pct", C.c_double), ("wave_us_mean", C.c_double), ("wave_us_max", C.c_double)]
+
+
 class _SynthParams(C.Structure):  # flex_synth_params
     _fields_ = [("n", C.c_int64), ("nnz", C.c_int64), ("alpha", C.c_double),
                 ("community", C.c_int64), ("p_in", C.c_double), ("p_near", C.c_double),
@@ -86,7 +92,7 @@ class _SynthParams(C.Structure):  # flex_synth_params
 # every symbol include/flex_spmm.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = [
     "flex_plan_create", "flex_plan_create_ex", "flex_plan_create_ld", "flex_plan_create_mapped", "flex_plan_create_rows", "flex_spmm",
-    "flex_plan_destroy", "flex_plan_get_info", "flex_plan_get_stats", "flex_plan_self_check", "flex_plan_kernel_info", "flex_hbm_probe", "flex_gather_rows", "flex_csv_load", "flex_mtx_load",
+    "flex_plan_destroy", "flex_plan_measure_imbalance", "flex_plan_get_info", "flex_plan_get_stats", "flex_plan_self_check", "flex_plan_kernel_info", "flex_hbm_probe", "flex_gather_rows", "flex_csv_load", "flex_mtx_load",
     "flex_csv_save", "flex_csr_save_bin", "flex_csr_load_bin", "flex_csr_fingerprint", "flex_perm_save", "flex_perm_load",
     "flex_host_csr_free", "flex_fill_dense_rand", "flex_order_rcm", "flex_order_cluster", "flex_order_gorder", "flex_perm_csr",
     "flex_order_deg", "flex_order_dfs", "flex_shard_rows", "flex_synth_graph", "flex_synth_preset", "flex_strerror", "flex_last_hip_error",
@@ -134,6 +140,7 @@ def lib():
         L.flex_plan_get_info.argtypes = [vp, C.POINTER(_PlanInfo)]
         L.flex_plan_get_stats.argtypes = [vp, C.POINTER(_PlanStats)]
         L.flex_plan_self_check.argtypes = [vp]
+        L.flex_plan_measure_imbalance.argtypes = [vp, vp, vp, vp, C.POINTER(_Imbalance)]
         L.flex_plan_kernel_info.argtypes = [vp, C.POINTER(_KernelInfo)]
         L.flex_gather_rows.argtypes = [vp, vp, vp, i64, i32, vp]
         L.flex_hbm_probe.argtypes = [i32, i64, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -393,6 +400,12 @@ class Plan:
         ki = _KernelInfo()
         _check(lib().flex_plan_kernel_info(self._h, C.byref(ki)), "flex_plan_kernel_info")
         return {f: getattr(ki, f) for f, _ in _KernelInfo._fields_}
+
+    def measure_imbalance(self, dB_ptr: int, dC_ptr: int, stream: int = 0) -> dict:
+        """flex_plan_measure_imbalance (≙ the per-SM "Imb" column, flex.cu:5087-5126): one stamped launch, per-CU / per-XCD busy imbalance."""
+        im = _Imbalance()
+        _check(lib().flex_plan_measure_imbalance(self._h, dB_ptr, dC_ptr, stream, C.byref(im)), "flex_plan_measure_imbalance")
+        return {f: getattr(im, f) for f, _ in _Imbalance._fields_}
 
     def self_check(self):
         """flex_plan_self_check: the device image of the plan is a partition of the work (raises FlexError if not)."""

@@ -93,6 +93,7 @@ struct Row {
     int errs;
     flex_plan_info info;
     flex_plan_stats stats;
+    flex_imbalance imb;  // ≙ the "Imb" column (flex.cu:5087-5126): one stamped launch after the timed ones
 };
 
 void bench_one(DataLoader &dl, unsigned schedule, const char *sched_name, const DataLoader &gold_src, float *h_res,
@@ -130,8 +131,10 @@ void bench_one(DataLoader &dl, unsigned schedule, const char *sched_name, const 
     if (!gold_src.h_ref_c.empty()) errs = resCheck(gold_src.h_ref_c.data(), h_res, mat, perfRes, &max_err);
     const double flops = 2.0 * dl.nnz * dl.dim;
     const double balg = (double(dl.n) + 1 + 2.0 * dl.nnz + 2.0 * dl.n * dl.dim) * 4;  // flex.cu:4672, 5795
+    flex_imbalance imb{};
+    if (flex_plan_measure_imbalance(mat.plan, mat.mat_b_dev, mat.mat_c_dev, nullptr, &imb) != FLEX_OK) imb = flex_imbalance{};  // odd k: no stamped twin
     rows.push_back({dl.vertex_order_abbr, sched_name, t_us, flops / t_us * 1e-3, balg / t_us * 1e-3,
-                    mat.info().plan_ms, max_err, errs, mat.info(), mat.stats()});
+                    mat.info().plan_ms, max_err, errs, mat.info(), mat.stats(), imb});
     perfRes.flex_spmm_time.push_back(static_cast<float>(t_us * 1e-3));
     mat.alpha_freeMatGPU();
 }
@@ -198,20 +201,25 @@ void run(DataLoader &input_vo) {
                     perfRes.cuSpmmProcessing, flops / perfRes.cuSpmmProcessing * 1e-3);
     // B-Re1 / B-Re2 as in the reference's table (flex.cu:5217-5223): nnz per distinct B row inside one
     // unit of work (here a chunk = one wave) and inside one cache domain (here an XCD's L2)
-    std::printf("%-4s %-8s %10s %10s %10s %8s %8s %8s %7s %7s %8s %9s\n", "Ord", "sched", "t/us", "GFLOP/s", "Balg GB/s",
-                "%8TB/s", "chunks", "split", "B-Re1", "B-Re2", "plan/ms", "errs");
+    // Imb = per-CU busy imbalance measured by wave clocks (≙ the reference's per-SM "Imb", flex.cu:5087-5126);
+    // tPre/tE = planning time over one execution (≙ the README's tPre/tElap column, README.md:34-42)
+    std::printf("%-4s %-8s %10s %10s %10s %8s %8s %8s %7s %7s %6s %8s %8s %9s\n", "Ord", "sched", "t/us", "GFLOP/s", "Balg GB/s",
+                "%8TB/s", "chunks", "split", "B-Re1", "B-Re2", "Imb%", "plan/ms", "tPre/tE", "errs");
     for (const Row &r : rows) {
-        std::printf("%-4s %-8s %10.1f %10.1f %10.1f %8.2f %8lld %8lld %7.2f %7.2f %8.1f %9d\n", r.ord.c_str(),
+        std::printf("%-4s %-8s %10.1f %10.1f %10.1f %8.2f %8lld %8lld %7.2f %7.2f %6.1f %8.1f %8.1f %9d\n", r.ord.c_str(),
                     r.sched.c_str(), r.t_us, r.gflops, r.balg_gbs, r.balg_gbs / 8000.0 * 100,
                     static_cast<long long>(r.info.n_chunks), static_cast<long long>(r.info.n_split_rows),
-                    r.stats.reuse_wave, r.stats.reuse_xcd, r.plan_ms, r.errs);
+                    r.stats.reuse_wave, r.stats.reuse_xcd, r.imb.cu_busy_imb_pct, r.plan_ms, r.plan_ms * 1e3 / r.t_us, r.errs);
         if (o.json)
             std::printf("{\"graph\":\"%s\",\"n\":%zu,\"nnz\":%zu,\"k\":%zu,\"ord\":\"%s\",\"schedule\":\"%s\",\"t_us\":%.3f,"
                         "\"gflops\":%.2f,\"balg_gbs\":%.2f,\"max_err\":%.3g,\"errs\":%d,\"vendor_us\":%.3f,\"b_re1\":%.3f,\"b_re2\":%.3f,"
-                        "\"chunk_imb_pct\":%.1f,\"xcd_imb_pct\":%.2f}\n",
+                        "\"chunk_imb_pct\":%.1f,\"xcd_imb_pct\":%.2f,\"cu_imb_pct\":%.2f,\"cu_end_spread_pct\":%.2f,\"xcd_busy_imb_pct\":%.2f,"
+                        "\"cus_seen\":%d,\"plan_ms\":%.2f,\"tpre_over_telap\":%.1f,\"mfma_tiles\":%lld,\"tile_nnz_pct_25\":%.2f}\n",
                         input_vo.graph_name.c_str(), input_vo.n, input_vo.nnz, input_vo.dim, r.ord.c_str(),
                         r.sched.c_str(), r.t_us, r.gflops, r.balg_gbs, r.max_err, r.errs, perfRes.cuSpmmProcessing,
-                        r.stats.reuse_wave, r.stats.reuse_xcd, r.stats.chunk_imb_pct, r.stats.xcd_imb_pct);
+                        r.stats.reuse_wave, r.stats.reuse_xcd, r.stats.chunk_imb_pct, r.stats.xcd_imb_pct, r.imb.cu_busy_imb_pct,
+                        r.imb.cu_end_spread_pct, r.imb.xcd_busy_imb_pct, r.imb.cus_seen, r.plan_ms, r.plan_ms * 1e3 / r.t_us,
+                        static_cast<long long>(r.stats.mfma_tiles), r.stats.tile_nnz_pct_25);
     }
     int mg_errs = 0;
     if (o.gpus > 0) {  // row-sharded over several GPUs (new; the reference is single-GPU, flex.cu:4137)

@@ -31,7 +31,7 @@ struct PlanView {
     uint32_t xcd_remap;      // 1: remap workgroup ids so each XCD walks one contiguous slice of the schedule
     uint32_t lds_extra;      // bytes of unused dynamic LDS per workgroup (occupancy throttle, tuning only)
     uint32_t rec_nt;         // 1: the record stream is read with non-temporal loads
-    uint64_t *trace;         // diagnostic builds (-DFLEX_TRACE) only: 6 words per wave; nullptr otherwise
+    uint64_t *trace;         // flex_plan_measure_imbalance: 3 words per (k-tile, chunk-table entry); diagnostic -DFLEX_TRACE builds: 12 per wave; else nullptr
 };
 
 
@@ -63,6 +63,7 @@ void note_hip_error(hipError_t e);
 // kernel launchers (spmm_kernels.hip)
 int launch_spmm(const PlanView &v, int lanes_per_nz, bool off32, bool vec4, const float *dB, float *dC,
                 hipStream_t s, int unroll = 0);
+int launch_spmm_stamped(const PlanView &v, int lanes_per_nz, bool off32, const float *dB, float *dC, hipStream_t s);
 int launch_fixup(const float *partial, const SplitRow *rows, uint32_t n_rows, int k, int ldc, float *dC,
                  hipStream_t s);
 int kernel_attributes(int lanes_per_nz, bool off32, bool vec4, hipFuncAttributes *attr, int *waves_per_cu);

@@ -1040,6 +1040,87 @@ int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream) {
     return rc;
 }
 
+int flex_plan_measure_imbalance(flex_plan *p, const float *dB, float *dC, flex_stream_t stream, flex_imbalance *out) try {
+    if (!p || !out || !dC || (!dB && p->nnz > 0)) return FLEX_ERR_INVALID;
+    *out = flex_imbalance{};
+    if (p->m == 0 || p->n_slots == 0) return FLEX_OK;
+    const bool vec4 = (p->k % 4 == 0) && (p->ldb % 4 == 0) && (p->ldc % 4 == 0) &&
+                      ((reinterpret_cast<uintptr_t>(dB) | reinterpret_cast<uintptr_t>(dC)) % 16 == 0);
+    if (!vec4) return FLEX_ERR_UNSUPPORTED;  // the stamped twin exists for the vector kernel only
+    int cur = -1;
+    FLEX_HIP_TRY(hipGetDevice(&cur));
+    if (cur != p->device) FLEX_HIP_TRY(hipSetDevice(p->device));
+    const size_t ktiles = (static_cast<size_t>(p->k) + 4 * p->lanes_per_nz - 1) / (4 * p->lanes_per_nz);
+    const size_t words = static_cast<size_t>(p->n_slots) * ktiles * 3;
+    uint64_t *d_log = nullptr;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int rc = FLEX_OK;
+    std::vector<uint64_t> log(words);
+    if (hipMalloc(reinterpret_cast<void **>(&d_log), words * 8) != hipSuccess) rc = FLEX_ERR_HIP;
+    if (!rc && hipMemsetAsync(d_log, 0, words * 8, s) != hipSuccess) rc = FLEX_ERR_HIP;
+    if (!rc) {
+        PlanView v{p->d_rec, p->d_t_beg, p->d_t_dst, p->d_t_aux, p->d_chunk, p->d_partial, p->d_split, p->d_split_cnt,
+                   p->fused_fixup ? 1u : 0u, p->n_slots, p->k, p->ldb, p->ldc, p->xcd_remap ? 1u : 0u, p->lds_extra, p->rec_nt ? 1u : 0u, d_log};
+        rc = launch_spmm_stamped(v, p->lanes_per_nz, p->off32, dB, dC, s);
+        if (rc == FLEX_OK && !p->fused_fixup) rc = launch_fixup(p->d_partial, p->d_split, p->n_split, p->k, p->ldc, dC, s);
+        if (rc == FLEX_OK && p->n_tiles) {
+            const TileView tv{p->d_tile_a, p->d_tile_boff, p->d_rt_ptr, p->d_rt_rows, p->n_row_tiles};
+            rc = launch_tiles(tv, p->off32, dB, dC, p->k, p->ldb, p->ldc, s);
+        }
+    }
+    if (!rc && (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(log.data(), d_log, words * 8, hipMemcpyDeviceToHost) != hipSuccess)) rc = FLEX_ERR_HIP;
+    (void)hipFree(d_log);
+    if (cur != p->device) (void)hipSetDevice(cur);
+    if (rc) return rc;
+    // reduce: CU = (XCC id, SE/SH/CU bits of HW_ID [15:8]); clock = 100 MHz
+    struct Acc {
+        uint64_t busy = 0, first = ~0ull, last = 0;
+    };
+    std::vector<Acc> cu(16 * 256), xcd(16);
+    uint64_t t_min = ~0ull, t_max = 0, busy_all = 0, w_max = 0;
+    int64_t waves = 0;
+    for (size_t i = 0; i < words; i += 3) {
+        const uint64_t t0 = log[i], t1 = log[i + 1], id = log[i + 2];
+        if (t1 == 0 || t1 < t0) continue;  // a padding entry of the chunk table: the wave left before the stamps
+        const uint32_t x = static_cast<uint32_t>(id >> 32) & 15u, c = (static_cast<uint32_t>(id) >> 8) & 255u;
+        for (Acc *a : {&cu[x * 256 + c], &xcd[x]}) {
+            a->busy += t1 - t0;
+            a->first = std::min(a->first, t0);
+            a->last = std::max(a->last, t1);
+        }
+        t_min = std::min(t_min, t0);
+        t_max = std::max(t_max, t1);
+        busy_all += t1 - t0;
+        w_max = std::max(w_max, t1 - t0);
+        ++waves;
+    }
+    if (waves == 0) return FLEX_OK;
+    auto summarise = [&](const std::vector<Acc> &v, int32_t *seen, double *busy_imb, double *end_spread) {
+        uint64_t bmax = 0, bsum = 0, emin = ~0ull, emax = 0;
+        int cnt = 0;
+        for (const Acc &a : v) {
+            if (a.last == 0) continue;
+            ++cnt;
+            bmax = std::max(bmax, a.busy);
+            bsum += a.busy;
+            emin = std::min(emin, a.last);
+            emax = std::max(emax, a.last);
+        }
+        *seen = cnt;
+        *busy_imb = bsum ? 100.0 * bmax * cnt / bsum - 100.0 : 0.0;
+        *end_spread = t_max > t_min ? 100.0 * (emax - emin) / (t_max - t_min) : 0.0;
+    };
+    out->waves = waves;
+    out->span_us = (t_max - t_min) * 0.01;
+    summarise(cu, &out->cus_seen, &out->cu_busy_imb_pct, &out->cu_end_spread_pct);
+    summarise(xcd, &out->xcds_seen, &out->xcd_busy_imb_pct, &out->xcd_end_spread_pct);
+    out->wave_us_mean = busy_all * 0.01 / waves;
+    out->wave_us_max = w_max * 0.01;
+    return FLEX_OK;
+} catch (const std::bad_alloc &) {
+    return FLEX_ERR_NOMEM;
+}
+
 int flex_plan_destroy(flex_plan *p) {
     if (!p) return FLEX_OK;
     int cur = -1;

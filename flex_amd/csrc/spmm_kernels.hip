@@ -460,7 +460,10 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
 // contiguous eighth of the schedule with ONE cursor, and its resident waves form a sliding
 // window over neighbouring rows whose shared B rows stay in that XCD's 4 MiB L2.  (A
 // persistent variant with per-XCD ticket queues was measured and rejected: DESIGN.md 3.4.)
-template <int G, bool OFF32, int U, int WPB>
+// STAMP = true is the measuring twin of the product kernel (flex_plan_measure_imbalance; ≙ the reference's per-warp
+// %smid + clock() stamps, flex.cu:27-79): the same code plus, per wave, two reads of the 100 MHz constant clock and one
+// 24-byte record {start, end, XCC id << 32 | HW_ID}.  The product launches (flex_spmm) never use it.
+template <int G, bool OFF32, int U, int WPB, bool STAMP = false>
 __global__ __launch_bounds__(64 * WPB) void spmm_flat_kernel(PlanView p, const float *__restrict__ B,
                                                              float *__restrict__ C) {
     __shared__ uint2 lds_rec[WPB][kWindowRecs];
@@ -506,7 +509,21 @@ __global__ __launch_bounds__(64 * WPB) void spmm_flat_kernel(PlanView p, const f
     const uint32_t my_beg = (static_cast<uint32_t>(lane) <= hdr.y) ? p.t_beg[hdr.x + lane] : 0u;
     const uint32_t my_dst = (static_cast<uint32_t>(lane) < hdr.y) ? p.t_dst[hdr.x + lane] : 0u;
     const uint2 my_aux = (static_cast<uint32_t>(lane) < hdr.y) ? p.t_aux[hdr.x + lane] : make_uint2(0u, 0u);  // read at chunk end only
+    uint64_t stamp_t0 = 0;
+    if constexpr (STAMP) stamp_t0 = __builtin_amdgcn_s_memrealtime();
     compute_chunk<G, OFF32, U>(p, hdr, my_beg, my_dst, my_aux, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok);
+    if constexpr (STAMP) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the wave's last stores have left
+        const uint64_t stamp_t1 = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0 && p.trace != nullptr) {
+            uint32_t hw_id;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+            uint64_t *log = p.trace + (static_cast<uint64_t>(blockIdx.y) * p.n_chunks + chunk) * 3;
+            log[0] = stamp_t0;
+            log[1] = stamp_t1;
+            log[2] = (static_cast<uint64_t>(xcc_id()) << 32) | hw_id;
+        }
+    }
 #endif
 }
 
@@ -615,6 +632,19 @@ int launch_v4(const PlanView &v, const float *dB, float *dC, hipStream_t s) {
 }
 
 template <int G, int U>
+int launch_stamped(const PlanView &v, bool off32, const float *dB, float *dC, hipStream_t s) {
+    uint32_t nblk = (v.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    nblk = (nblk + kXcds - 1) / kXcds * kXcds;
+    const uint32_t ktiles = (v.k + 4 * G - 1) / (4 * G);
+    if (off32)
+        hipLaunchKernelGGL((spmm_flat_kernel<G, true, U, kWavesPerBlock, true>), dim3(nblk, ktiles), dim3(64 * kWavesPerBlock), v.lds_extra, s, v, dB, dC);
+    else
+        hipLaunchKernelGGL((spmm_flat_kernel<G, false, U, kWavesPerBlock, true>), dim3(nblk, ktiles), dim3(64 * kWavesPerBlock), v.lds_extra, s, v, dB, dC);
+    FLEX_HIP_TRY(hipGetLastError());
+    return FLEX_OK;
+}
+
+template <int G, int U>
 int launch_v4_off(const PlanView &v, bool off32, const float *dB, float *dC, hipStream_t s) {
     return off32 ? launch_v4<G, true, U>(v, dB, dC, s) : launch_v4<G, false, U>(v, dB, dC, s);
 }
@@ -647,6 +677,18 @@ int launch_spmm(const PlanView &v, int lanes_per_nz, bool off32, bool vec4, cons
         case 16: return launch_v4_off<16, 4>(v, off32, dB, dC, s);
         case 32: return launch_v4_off<32, 8>(v, off32, dB, dC, s);
         case 64: return launch_v4_off<64, 8>(v, off32, dB, dC, s);
+        default: return FLEX_ERR_UNSUPPORTED;
+    }
+}
+
+// the stamped twin of what launch_spmm launches for aligned operands (v.trace must hold 3 words per (k-tile, chunk-table entry))
+int launch_spmm_stamped(const PlanView &v, int lanes_per_nz, bool off32, const float *dB, float *dC, hipStream_t s) {
+    if (v.n_chunks == 0) return FLEX_OK;
+    switch (lanes_per_nz) {
+        case 8: return launch_stamped<8, 4>(v, off32, dB, dC, s);
+        case 16: return launch_stamped<16, 4>(v, off32, dB, dC, s);
+        case 32: return launch_stamped<32, 8>(v, off32, dB, dC, s);
+        case 64: return launch_stamped<64, 8>(v, off32, dB, dC, s);
         default: return FLEX_ERR_UNSUPPORTED;
     }
 }

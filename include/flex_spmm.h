@@ -180,6 +180,24 @@ typedef struct flex_plan_stats {
 } flex_plan_stats;
 int flex_plan_get_stats(const flex_plan *plan, flex_plan_stats *out);
 
+/* ≙ the per-SM imbalance column of run()'s table (flex.cu:27-79 stamps %smid + clock() per warp, flex.cu:5087-5126
+ * turns them into "Imb"): ONE extra launch of the plan with the stamped twin of the SpMM kernel (every wave records the
+ * 100 MHz constant clock at start and end and the CU it ran on: XCC id + HW_ID), reduced on the host.  dB / dC as for
+ * flex_spmm (16-byte aligned, k % 4 == 0; dC receives the ordinary result); synchronises `stream`.  Not part of
+ * flex_spmm: the product launch carries no stamps. */
+typedef struct flex_imbalance {
+    int64_t waves;            /* waves that ran (chunk-table entries x column tiles, minus padding entries) */
+    int32_t cus_seen;         /* distinct CUs that ran at least one wave (256 on MI355X) */
+    int32_t xcds_seen;
+    double span_us;           /* first wave start -> last wave end */
+    double cu_busy_imb_pct;   /* per CU: sum of its waves' lifetimes; 100 max/mean - 100   (≙ "Imb") */
+    double cu_end_spread_pct; /* 100 (latest CU end - earliest CU end) / span: how long the first idle CU waits for the last */
+    double xcd_busy_imb_pct;  /* the same sums per XCD */
+    double xcd_end_spread_pct;
+    double wave_us_mean, wave_us_max;
+} flex_imbalance;
+int flex_plan_measure_imbalance(flex_plan *plan, const float *dB, float *dC, flex_stream_t stream, flex_imbalance *out);
+
 /* ≙ Kernel_Info / GPU_Info (flex.cu:4127-4142, 4933-4941: "Kernel %s: %d regs, %zd local, %zd B shared"): what
  * the kernel this plan launches (for 16-byte aligned dense operands) costs per wave and how many waves fit a CU. */
 typedef struct flex_kernel_info {

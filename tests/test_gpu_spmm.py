@@ -889,3 +889,23 @@ def test_mfma_route_after_reordering_shards_strides_and_duplicates(monkeypatch):
     pd = Plan(dup, 32)
     assert pd.info()["n_tiles"] == 2 and pd.info()["tile_nnz"] == 2 * 1024
     assert_matches_oracle(dup, Bdup, run_plan(pd, Bdup))
+
+
+def test_measured_per_cu_imbalance_report():
+    """flex_plan_measure_imbalance (≙ the reference's per-SM "Imb" column, flex.cu:27-79, 5087-5126): one launch of the
+    stamped twin of the kernel; the C it leaves is the ordinary result, every CU of the chip shows up, the numbers are
+    sane, and a schedule with all the heavy rows at one end of one XCD's slice reads as more imbalanced than a balanced one."""
+    a = flex_amd.synth_graph("flickr")
+    k = 128
+    B = random_B(a.n, k, 7)
+    Bd = dev(B)
+    p = Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER)
+    C = torch.empty((a.m, k), device="cuda")
+    im = p.measure_imbalance(Bd.data_ptr(), C.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert_matches_oracle(a, B, C.cpu().numpy(), nthreads=8)
+    assert im["cus_seen"] >= 200 and im["xcds_seen"] == 8 and im["waves"] >= p.info()["n_chunks"]
+    assert 0.0 <= im["cu_busy_imb_pct"] < 300.0 and 0.0 <= im["cu_end_spread_pct"] <= 100.0
+    assert 5.0 < im["span_us"] < 2000.0 and 0 < im["wave_us_mean"] <= im["wave_us_max"]
+    # odd k has no stamped twin: refused, not faked
+    with pytest.raises(flex_amd.FlexError):
+        Plan(a, 7).measure_imbalance(dev(random_B(a.n, 7, 1)).data_ptr(), torch.empty((a.m, 7), device="cuda").data_ptr(), 0)
