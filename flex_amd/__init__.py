@@ -36,6 +36,7 @@ from .binding import (  # noqa: F401
     order_deg,
     order_dfs,
     order_gorder,
+    order_rabbit,
     synth_preset,
     perm_csr,
     shard_rows,

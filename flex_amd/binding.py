@@ -95,7 +95,7 @@ SYMBOLS = [
     "flex_plan_destroy", "flex_plan_measure_imbalance", "flex_plan_get_info", "flex_plan_get_stats", "flex_plan_self_check", "flex_plan_kernel_info", "flex_hbm_probe", "flex_gather_rows", "flex_csv_load", "flex_mtx_load",
     "flex_csv_save", "flex_csr_save_bin", "flex_csr_load_bin", "flex_csr_fingerprint", "flex_perm_save", "flex_perm_load",
     "flex_host_csr_free", "flex_fill_dense_rand", "flex_order_rcm", "flex_order_cluster", "flex_order_gorder", "flex_perm_csr",
-    "flex_order_deg", "flex_order_dfs", "flex_shard_rows", "flex_synth_graph", "flex_synth_preset", "flex_strerror", "flex_last_hip_error",
+    "flex_order_deg", "flex_order_dfs", "flex_order_rabbit", "flex_shard_rows", "flex_synth_graph", "flex_synth_preset", "flex_strerror", "flex_last_hip_error",
     "flex_last_hip_error_string", "flex_abi_version",
 ]
 
@@ -160,6 +160,7 @@ def lib():
         L.flex_order_cluster.argtypes = [C.POINTER(_Csr), vp]
         L.flex_order_gorder.argtypes = [C.POINTER(_Csr), u32, vp]
         L.flex_order_dfs.argtypes = [C.POINTER(_Csr), vp]
+        L.flex_order_rabbit.argtypes = [C.POINTER(_Csr), i32, vp]
         L.flex_order_deg.argtypes = [C.POINTER(_Csr), i32, vp]
         L.flex_synth_preset.argtypes = [C.c_char_p, i32, C.POINTER(_SynthParams)]
         L.flex_perm_csr.argtypes = [C.POINTER(_Csr), vp, vp, vp, vp, vp]
@@ -339,6 +340,16 @@ def order_dfs(a: HostCsr) -> np.ndarray:
     rank = np.empty(max(a.m, 1), dtype=np.uint32)
     v = a.view()
     _check(lib().flex_order_dfs(C.byref(v), rank.ctypes.data), "flex_order_dfs")
+    return rank[: a.m]
+
+
+def order_rabbit(a: HostCsr, is_directed: bool | None = None) -> np.ndarray:
+    """flex_order_rabbit: the reference's Rabbit order (DataLoader.cu:455-655); is_directed defaults to the loader's statistic."""
+    if is_directed is None:
+        is_directed = bool(getattr(a, "is_directed", 0))
+    rank = np.empty(max(a.m, 1), dtype=np.uint32)
+    v = a.view()
+    _check(lib().flex_order_rabbit(C.byref(v), int(bool(is_directed)), rank.ctypes.data), "flex_order_rabbit")
     return rank[: a.m]
 
 

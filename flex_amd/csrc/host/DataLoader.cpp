@@ -219,7 +219,16 @@ DataLoaderGorder::DataLoaderGorder(const DataLoader &dl) : DataLoader(dl) {
 }
 
 DataLoaderRabbit::DataLoaderRabbit(const DataLoader &dl) : DataLoader(dl) {
-    adopt_rank(dl, cached_rank(dl, "RBT", [](const flex_csr *a, uint32_t *r) { return flex_order_cluster(a, r); }), "RBT");
+    // the reference's own algorithm (flex_order_rabbit restates DataLoader.cu:455-655 merge for merge) on the sizes the
+    // reference runs it on; its per-vertex weight maps make it impractical past a few 10^7 nonzeros (the reference's too),
+    // where the engine's parallel clustering stands in -- said out loud, never silently
+    const bool is_dir = dl.is_directed;
+    if (dl.nnz <= 50'000'000) {
+        adopt_rank(dl, cached_rank(dl, "RBT", [is_dir](const flex_csr *a, uint32_t *r) { return flex_order_rabbit(a, is_dir ? 1 : 0, r); }), "RBT");
+    } else {
+        std::printf("RBT: %zu nonzeros is beyond the reference's map-based Rabbit; using the engine's parallel clustering (flex_order_cluster)\n", static_cast<size_t>(dl.nnz));
+        adopt_rank(dl, cached_rank(dl, "RBC", [](const flex_csr *a, uint32_t *r) { return flex_order_cluster(a, r); }), "RBT");
+    }
 }
 
 void DataLoader::getDegDist() {  // DataLoader.cu:126-145

@@ -84,7 +84,7 @@ class DataLoaderGorder : public DataLoader {  // DataLoader.cu:789-857 (window 3
    public:
     explicit DataLoaderGorder(const DataLoader &dl);
 };
-class DataLoaderRabbit : public DataLoader {  // DataLoader.cu:453-655 (community order; engine's own clustering)
+class DataLoaderRabbit : public DataLoader {  // DataLoader.cu:453-655 (flex_order_rabbit: the reference's merges and dendrogram walk)
    public:
     explicit DataLoaderRabbit(const DataLoader &dl);
 };

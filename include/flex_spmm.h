@@ -291,6 +291,11 @@ int flex_order_gorder(const flex_csr *A, uint32_t window, uint32_t *rank);
 
 /* ≙ the ordering of DataLoaderDFS (DataLoader.cu:324-395): depth-first pre-order from vertex 0. */
 int flex_order_dfs(const flex_csr *A, uint32_t *rank);
+/* ≙ DataLoaderRabbit (DataLoader.cu:455-655) as the reference compiles it (iterative rounds in degree order, no hub
+ * grouping): modularity-driven agglomeration + left-to-right walk of the dendrograms.  is_directed = the loader's flag
+ * (the clustering then runs on the undirected version).  rank[old] = new; identical to the oracle's restatement.
+ * The engine's own community schedule is flex_order_cluster (parallel, built for 10^8 nonzeros). */
+int flex_order_rabbit(const flex_csr *A, int is_directed, uint32_t *rank);
 
 /* ≙ order_deg(h, desc) (order_deg.cu:19-45): rank by in+out degree, ties by vertex id. */
 int flex_order_deg(const flex_csr *A, int descending, uint32_t *rank);

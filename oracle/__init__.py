@@ -61,6 +61,8 @@ def lib():
         L.oracle_order_gorder.restype = C.c_int
         L.oracle_order_dfs.argtypes = [C.c_int64, u32p, u32p, u64p]
         L.oracle_order_dfs.restype = C.c_int
+        L.oracle_order_rabbit.argtypes = [C.c_int64, u32p, u32p, C.c_int, u64p]
+        L.oracle_order_rabbit.restype = C.c_int
         L.oracle_mtx_load.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                       C.POINTER(u32p), C.POINTER(u32p), C.POINTER(f32p)]
         L.oracle_mtx_load.restype = C.c_int
@@ -156,6 +158,17 @@ def order_gorder(rowPtr, col, window: int = 3) -> np.ndarray:
     rc = lib().oracle_order_gorder(n, _p(rowPtr, C.c_uint32), _p(col, C.c_uint32), window, _p(rank, C.c_uint64))
     if rc:
         raise RuntimeError(f"oracle_order_gorder failed: {rc}")
+    return rank[:n]
+
+
+def order_rabbit(rowPtr, col, is_directed: bool) -> np.ndarray:
+    """DataLoaderRabbit (DataLoader.cu:455-655), rank[old] = new."""
+    rowPtr, col = _u32(rowPtr), _u32(col)
+    n = len(rowPtr) - 1
+    rank = np.empty(max(n, 1), dtype=np.uint64)
+    rc = lib().oracle_order_rabbit(n, _p(rowPtr, C.c_uint32), _p(col, C.c_uint32), int(bool(is_directed)), _p(rank, C.c_uint64))
+    if rc:
+        raise RuntimeError(f"oracle_order_rabbit failed: {rc}")
     return rank[:n]
 
 

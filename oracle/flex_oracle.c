@@ -702,6 +702,149 @@ int oracle_order_dfs(int64_t n, const uint32_t *rowPtr, const uint32_t *col, uin
     return 0;
 }
 
+/* ------------------------------------------------------------------ Rabbit */
+/* DataLoaderRabbit, DataLoader.cu:455-655 with its compile-time options as the reference sets them (opt_iterative = true,
+ * opt_hub_group = opt_hub_sort = false, cluster shyness 1): modularity-driven agglomeration in rounds.
+ *   - every vertex keeps a map neighbour -> weight (std::map<int,int> dst_wht: iteration in ascending key); weight 1 per
+ *     distinct neighbour, self loops left out, and for a directed graph (dl.is_directed) the reverse edge is added too
+ *     (force_undirected, :516-531); deg = number of distinct neighbours, n_edges = sum of deg, two_m_inv = 1/(2 n_edges);
+ *   - round: vertices of the round sorted by current deg (:545-546); u is skipped if it absorbed something this round
+ *     (:554); its target is the neighbour with the largest  w - deg[d] * deg[u] * two_m_inv,  first maximum in ascending
+ *     d (set_max is a strict >, common.h:101-107; start value -1), and only if that is > 0 (:556-560);
+ *   - merge u into v (:563-583): deg[v] += deg[u]; every (d,w) of u except d == v is added to v's map and, where d's map
+ *     holds u, that entry moves to v; u leaves v's map; dendrogram node (v's tree, u's tree) becomes v's tree (:586-588);
+ *     v enters the next round once (:590-592);
+ *   - order (:614-628, 633-648): vertices in index order that still own a tree, leaves left to right.
+ * rank[old] = new.  One liberty: the reference sorts a round with ranges::sort, which leaves the order of equal degrees to
+ * the library; here equal degrees keep the order they had in the list (a stable sort) -- the same rule in flex_order_rabbit. */
+typedef struct { uint32_t key; int32_t w; } rb_ent;
+typedef struct { rb_ent *e; uint32_t n, cap; } rb_map;
+
+static int64_t rb_find(const rb_map *m, uint32_t key) { /* index of key, or -(insertion point)-1 */
+    int64_t lo = 0, hi = (int64_t)m->n - 1;
+    while (lo <= hi) {
+        const int64_t mid = (lo + hi) / 2;
+        if (m->e[mid].key == key) return mid;
+        if (m->e[mid].key < key) lo = mid + 1; else hi = mid - 1;
+    }
+    return -lo - 1;
+}
+static int rb_add(rb_map *m, uint32_t key, int32_t w) { /* m[key] += w (creating it at 0) */
+    int64_t i = rb_find(m, key);
+    if (i >= 0) { m->e[i].w += w; return 0; }
+    i = -i - 1;
+    if (m->n == m->cap) {
+        const uint32_t cap = m->cap ? m->cap * 2 : 4;
+        rb_ent *e = (rb_ent *)realloc(m->e, sizeof(rb_ent) * cap);
+        if (!e) return -ENOMEM;
+        m->e = e; m->cap = cap;
+    }
+    memmove(m->e + i + 1, m->e + i, sizeof(rb_ent) * (m->n - (size_t)i));
+    m->e[i].key = key; m->e[i].w = w; m->n++;
+    return 0;
+}
+static void rb_erase(rb_map *m, uint32_t key) {
+    const int64_t i = rb_find(m, key);
+    if (i < 0) return;
+    memmove(m->e + i, m->e + i + 1, sizeof(rb_ent) * (m->n - (size_t)i - 1));
+    m->n--;
+}
+
+int oracle_order_rabbit(int64_t n, const uint32_t *rowPtr, const uint32_t *col, int is_directed, uint64_t *rank) {
+    if (n == 0) return 0;
+    rb_map *g = (rb_map *)calloc((size_t)n, sizeof(rb_map));
+    int64_t *deg = (int64_t *)calloc((size_t)n, sizeof(int64_t));
+    int32_t *round_of = (int32_t *)calloc((size_t)n, sizeof(int32_t));
+    /* dendrogram: node ids 0..n-1 are leaves, n+u is the cluster node made when u was merged away */
+    int64_t *lch = (int64_t *)malloc(sizeof(int64_t) * 2 * (size_t)n), *rch = (int64_t *)malloc(sizeof(int64_t) * 2 * (size_t)n);
+    int64_t *tree = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+    uint32_t *cur = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n), *nxt = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n);
+    uint32_t *tmp = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)n);
+    int64_t *stack = (int64_t *)malloc(sizeof(int64_t) * (2 * (size_t)n + 2));
+    if (!g || !deg || !round_of || !lch || !rch || !tree || !cur || !nxt || !tmp || !stack) return -ENOMEM;
+    int rc = 0;
+    for (int64_t v = 0; v < n && !rc; ++v)
+        for (uint32_t e = rowPtr[v]; e < rowPtr[v + 1] && !rc; ++e) {
+            const uint32_t d = col[e];
+            if (d == (uint32_t)v) continue;
+            int64_t i = rb_find(&g[v], d);
+            if (i < 0) rc = rb_add(&g[v], d, 1); /* dst_wht[d] = 1 (an assignment: duplicates do not add up) */
+            if (is_directed && !rc && rb_find(&g[d], (uint32_t)v) < 0) rc = rb_add(&g[d], (uint32_t)v, 1);
+        }
+    int64_t n_edges = 0;
+    for (int64_t v = 0; v < n; ++v) {
+        deg[v] = g[v].n;
+        n_edges += deg[v];
+        tree[v] = v;
+        lch[v] = rch[v] = -1;
+        cur[v] = (uint32_t)v;
+    }
+    const double two_m_inv = 1.0 / (double)(2 * n_edges);
+    size_t n_cur = (size_t)n;
+    for (int32_t round = 1; n_cur > 0 && !rc; ++round) {
+        /* stable sort of the round's vertices by current degree (bottom-up merge sort) */
+        for (size_t w = 1; w < n_cur; w *= 2) {
+            for (size_t lo = 0; lo < n_cur; lo += 2 * w) {
+                const size_t mid = lo + w < n_cur ? lo + w : n_cur, hi = lo + 2 * w < n_cur ? lo + 2 * w : n_cur;
+                size_t a = lo, b = mid, o = lo;
+                while (a < mid && b < hi) tmp[o++] = deg[cur[b]] < deg[cur[a]] ? cur[b++] : cur[a++];
+                while (a < mid) tmp[o++] = cur[a++];
+                while (b < hi) tmp[o++] = cur[b++];
+            }
+            uint32_t *sw = cur; cur = tmp; tmp = sw;
+        }
+        size_t n_nxt = 0;
+        for (size_t idx = 0; idx < n_cur && !rc; ++idx) {
+            const uint32_t u = cur[idx];
+            if (round_of[u] == round) continue;
+            double dq_max = -1.0;
+            int64_t v = -1;
+            const double dv_2m = (double)deg[u] * two_m_inv;
+            for (uint32_t i = 0; i < g[u].n; ++i) {
+                const double q = (double)g[u].e[i].w - (double)deg[g[u].e[i].key] * dv_2m;
+                if (q > dq_max) { dq_max = q; v = g[u].e[i].key; }
+            }
+            if (dq_max <= 0.0) continue;
+            deg[v] += deg[u];
+            for (uint32_t i = 0; i < g[u].n && !rc; ++i) {
+                const uint32_t d = g[u].e[i].key;
+                if (d == (uint32_t)v) continue;
+                rc = rb_add(&g[v], d, g[u].e[i].w);
+                const int64_t j = rb_find(&g[d], u);
+                if (j < 0 || rc) continue;
+                const int32_t wu = g[d].e[j].w;
+                rc = rb_add(&g[d], (uint32_t)v, wu);
+                rb_erase(&g[d], u);
+            }
+            rb_erase(&g[v], u);
+            lch[n + u] = tree[v];
+            rch[n + u] = tree[u];
+            tree[u] = -1;
+            tree[v] = n + u;
+            if (round_of[v] == round) continue;
+            round_of[v] = round;
+            nxt[n_nxt++] = (uint32_t)v;
+        }
+        uint32_t *sw = cur; cur = nxt; nxt = sw;
+        n_cur = n_nxt;
+    }
+    uint64_t next_id = 0;
+    for (int64_t v = 0; v < n && !rc; ++v) {
+        if (tree[v] < 0) continue;
+        int64_t sp = 0;
+        stack[sp++] = tree[v];
+        while (sp > 0) { /* leaves left to right */
+            const int64_t t = stack[--sp];
+            if (t < n) { rank[t] = next_id++; continue; }
+            stack[sp++] = rch[t];
+            stack[sp++] = lch[t];
+        }
+    }
+    for (int64_t v = 0; v < n; ++v) free(g[v].e);
+    free(g); free(deg); free(round_of); free(lch); free(rch); free(tree); free(cur); free(nxt); free(tmp); free(stack);
+    return rc;
+}
+
 /* --------------------------------------------------------- MatrixMarket -> CSR */
 /* mmio_allinone, data/SuiteSparse/mtx2csr.cc:57-247: coordinate entries read with fscanf in file
  * order ("%d %d %lg" real, "%d %d %lg %lg" complex keeping the real part, "%d %d %d" integer,

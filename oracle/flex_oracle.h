@@ -84,6 +84,8 @@ void oracle_free(void *p);
 
 /* DataLoaderDFS ordering, DataLoader.cu:324-395: depth-first discovery order from vertex 0. */
 int oracle_order_dfs(int64_t n, const uint32_t *rowPtr, const uint32_t *col, uint64_t *rank);
+/* DataLoaderRabbit (DataLoader.cu:455-655), options as compiled in the reference; rank[old] = new */
+int oracle_order_rabbit(int64_t n, const uint32_t *rowPtr, const uint32_t *col, int is_directed, uint64_t *rank);
 
 /* DataLoaderRcm / DataLoaderGorder body, DataLoader.cu:741-779 / 815-850: given
  * rank[old]=new, build vo_mp[new]=old and the permuted CSR with columns mapped and

@@ -216,3 +216,35 @@ def test_dfs_order_equals_oracle_and_is_a_preorder():
     # a path 0->2->1 plus an unreachable vertex 3: discovery order 0,2,1 then the next root 3
     p = flex_amd.HostCsr([0, 1, 1, 2, 2], [2, 1], [1.0, 1.0])
     assert flex_amd.order_dfs(p).tolist() == [0, 2, 1, 3]
+
+
+def test_rabbit_order_equals_oracle_restatement():
+    """flex_order_rabbit (product, C++) against the oracle's literal restatement of DataLoaderRabbit
+    (DataLoader.cu:455-655): the same rank vertex for vertex on the reference's two data files, on undirected and directed
+    synthetic graphs, and on hand-made cases (two triangles joined by an edge; isolated vertices; duplicate entries)."""
+    cases = [flex_amd.csv_load(os.path.join(GOLDEN, "pubmed.csv")), flex_amd.csv_load(os.path.join(GOLDEN, "a_mat.csv")),
+             flex_amd.synth_graph(n=3000, nnz=3000 + 2 * 20000, community=60, p_in=0.6, p_near=0.2, seed=9),
+             flex_amd.synth_graph(n=2500, nnz=30000, community=50, p_in=0.5, p_near=0.2, seed=10, directed=True, gcn_norm=False)]
+    for a in cases:
+        r = flex_amd.order_rabbit(a)
+        assert sorted(r.tolist()) == list(range(a.m))
+        assert np.array_equal(r.astype(np.uint64), oracle.order_rabbit(a.rowPtr, a.col, bool(a.is_directed)))
+    # two triangles {0,1,2} and {3,4,5} joined by the edge 2-3: each triangle ends up contiguous
+    edges = [(0, 1), (1, 2), (0, 2), (3, 4), (4, 5), (3, 5), (2, 3)]
+    adj = [[] for _ in range(6)]
+    for u, v in edges:
+        adj[u].append(v)
+        adj[v].append(u)
+    rp = np.cumsum([0] + [len(x) for x in adj]).astype(np.uint32)
+    tri = flex_amd.HostCsr(rp, np.concatenate([sorted(x) for x in adj]).astype(np.uint32), np.ones(rp[-1], np.float32))
+    r = flex_amd.order_rabbit(tri, False)
+    assert np.array_equal(r.astype(np.uint64), oracle.order_rabbit(tri.rowPtr, tri.col, False))
+    assert {int(r[0]) // 3, int(r[1]) // 3, int(r[2]) // 3} in ({0}, {1}) and {int(r[3]) // 3, int(r[4]) // 3, int(r[5]) // 3} in ({0}, {1})
+    # isolated vertices, a self loop, a duplicate entry: they keep their place in index order
+    odd = flex_amd.HostCsr([0, 2, 4, 5, 5, 6], [1, 1, 0, 0, 2, 4], [1, 1, 1, 1, 1, 1])
+    assert np.array_equal(flex_amd.order_rabbit(odd, False).astype(np.uint64), oracle.order_rabbit(odd.rowPtr, odd.col, False))
+    # locality: on a shuffled community graph the order pulls neighbours together
+    g = cases[2]
+    rows = np.repeat(np.arange(g.m), np.diff(g.rowPtr.astype(np.int64)))
+    rk = flex_amd.order_rabbit(g).astype(np.int64)
+    assert np.mean(np.abs(rk[rows] - rk[g.col]) <= 64) > 3 * np.mean(np.abs(rows - g.col.astype(np.int64)) <= 64)
