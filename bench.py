@@ -226,6 +226,8 @@ def main():
         b_alg = 4.0 * (shard_rows + 1) + 8.0 * shard_nnz + 4.0 * a.n * k + 4.0 * shard_rows * k
         kern_ms = dev_ms / args.steps
         achieved = b_alg / (kern_ms * 1e-3) / 1e9
+        g_lanes = max(info["lanes_per_nz"], 1)
+        gather_demand = float(info.get("n_records", shard_nnz)) * 16.0 * g_lanes * -(-k // (4 * g_lanes))
         out = {
             "metric": "SpMM GFLOPS (2*nnz*k/t)", "value": round(gflops, 2), "unit": "GFLOPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -247,7 +249,13 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(args, world),
                          "kernel": "spmm_flat_kernel", "kernel_ms": round(kern_ms, 6),
-                         "algorithmic_bytes_per_launch": int(b_alg)},
+                         "algorithmic_bytes_per_launch": int(b_alg),
+                         # the roof that binds high-degree graphs: every record pulls one B-row segment of
+                         # 16*G bytes through a CU's texture path, once per column tile, whether it hits the L2 or not;
+                         # MI355X_MICROARCH.md measures 16.8-18.8 TB/s chip-wide for L2-served row gathers
+                         "gather_demand_bytes_per_launch": int(gather_demand),
+                         "gather_rate_GBps": round(gather_demand / (kern_ms * 1e-3) / 1e9, 1),
+                         "l2_gather_rate_measured_GBps": [16800, 18800]},
         }
         if per_rank is not None:
             nnzs = [r[2] for r in per_rank]

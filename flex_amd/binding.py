@@ -51,7 +51,7 @@ class _PlanInfo(C.Structure):  # flex_plan_info
                 ("n_split_rows", C.c_int64), ("n_partials", C.c_int64),
                 ("device_bytes", C.c_int64), ("lanes_per_nz", C.c_int32), ("order", C.c_int32),
                 ("plan_ms", C.c_double), ("n_slots", C.c_int64), ("two_d", C.c_int32), ("panel_rows", C.c_int32),
-                ("n_tiles", C.c_int64), ("tile_nnz", C.c_int64)]
+                ("n_tiles", C.c_int64), ("tile_nnz", C.c_int64), ("n_records", C.c_int64)]
 
 
 class _PlanStats(C.Structure):  # flex_plan_stats

@@ -1151,6 +1151,7 @@ int flex_plan_get_info(const flex_plan *p, flex_plan_info *o) {
     o->two_d = p->two_d ? 1 : 0;
     o->n_tiles = p->n_tiles;
     o->tile_nnz = p->tile_nnz;
+    o->n_records = static_cast<int64_t>(p->n_records);
     o->panel_rows = p->two_d ? static_cast<int32_t>(p->panel_rows) : 0;
     return FLEX_OK;
 }
@@ -1252,6 +1253,29 @@ int flex_plan_self_check(const flex_plan *p) try {
         first += sr.count;
     }
     if (first != p->n_partials) return FLEX_ERR_FORMAT;
+    // dense tiles: the row-tile directory tiles the tile list, every listed C row is valid and named by one row tile only,
+    // every tile column names a valid B row
+    if (p->n_tiles) {
+        std::vector<uint32_t> rt_ptr(static_cast<size_t>(p->n_row_tiles) + 1), rt_rows(static_cast<size_t>(p->n_row_tiles) * 32),
+            boff(static_cast<size_t>(p->n_tiles) * 32);
+        if (cur != p->device) FLEX_HIP_TRY(hipSetDevice(p->device));
+        const bool ok_t = down(rt_ptr.data(), p->d_rt_ptr, rt_ptr.size() * 4) && down(rt_rows.data(), p->d_rt_rows, rt_rows.size() * 4) &&
+                          down(boff.data(), p->d_tile_boff, boff.size() * 4);
+        if (cur != p->device) (void)hipSetDevice(cur);
+        if (!ok_t) return FLEX_ERR_HIP;
+        if (rt_ptr[0] != 0 || rt_ptr[p->n_row_tiles] != p->n_tiles) return FLEX_ERR_FORMAT;
+        for (uint32_t i = 0; i < p->n_row_tiles; ++i)
+            if (rt_ptr[i] >= rt_ptr[i + 1]) return FLEX_ERR_FORMAT;
+        std::vector<uint8_t> in_rt(static_cast<size_t>(p->c_rows), 0);
+        for (uint32_t d : rt_rows) {
+            if (d == 0xFFFFFFFFu) continue;
+            if (d >= p->c_rows || in_rt[d]++) return FLEX_ERR_FORMAT;
+        }
+        for (uint32_t o : boff) {
+            const uint64_t col = p->off32 ? o / row_bytes : o;
+            if (col >= static_cast<uint64_t>(p->n) || (p->off32 && o % row_bytes != 0)) return FLEX_ERR_FORMAT;
+        }
+    }
     // a full plan (not a row shard of a mapped matrix) writes every row of C
     if (p->c_rows == p->m)
         for (uint8_t w : written)

@@ -146,6 +146,7 @@ typedef struct flex_plan_info {
     int32_t panel_rows;   /* two_d: B rows per column panel (a power of two), else 0 */
     int64_t n_tiles;      /* dense 32x32 tiles of A routed to the MFMA kernel (0: the vector kernel does everything) */
     int64_t tile_nnz;     /* nonzeros held by those tiles */
+    int64_t n_records;    /* (col,val) records the vector kernel streams per column tile: nnz - tile_nnz + padding */
 } flex_plan_info;
 int flex_plan_get_info(const flex_plan *plan, flex_plan_info *out);
 
