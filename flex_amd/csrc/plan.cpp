@@ -465,12 +465,16 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     const uint32_t row_cost = static_cast<uint32_t>(env_long("FLEX_ROW_COST", 16));
     p->xcd_remap = env_long("FLEX_XCD_REMAP", 1) != 2;  // 2 = off (tuning experiments only)
     p->lds_extra = static_cast<unsigned>(env_long("FLEX_LDS_EXTRA", 1)) & ~15u;  // default 0 (1 -> 0)
-    // the record stream is read once per column tile: non-temporal loads keep it from displacing B rows in the L2s and
-    // the Infinity Cache.  Measured (tools/probe_2d.py): amazon shape 9.48 -> 9.00 ms, reddit 697 -> 688 us;
-    // on by default once the stream is large against the caches (>= 32 MB), FLEX_REC_NT = 1 / 2 forces it on / off
+    // The record stream is read once per column tile.  When a launch has SEVERAL tiles (k > 4G) and the stream is large
+    // against the caches (>= 32 MB), non-temporal loads keep one tile's pass over the records from displacing B rows in the
+    // L2s and the Infinity Cache: amazon shape k=128 9.48 -> 9.00 ms, reddit 687 -> 679 us, yelp 524 -> 515 us.  With ONE
+    // tile the same loads cost time instead (they sit on the header -> records -> gathers chain of every chunk and come
+    // back slower): reddit k=32 178 -> 196 us, yelp k=32 130 -> 148 us, flickr k=128 37.9 -> 40.4 us (same box, DESIGN.md
+    // 3.4).  FLEX_REC_NT = 1 / 2 forces them on / off.
     {
         const long nt_env = env_long("FLEX_REC_NT", 0);
-        p->rec_nt = nt_env == 1 || (nt_env != 2 && static_cast<uint64_t>(A->rowPtr[r1] - A->rowPtr[r0]) * 8u >= (32u << 20));
+        const int ktiles_nt = (k + 4 * G - 1) / (4 * G);
+        p->rec_nt = nt_env == 1 || (nt_env != 2 && ktiles_nt >= 2 && static_cast<uint64_t>(A->rowPtr[r1] - A->rowPtr[r0]) * 8u >= (32u << 20));
     }
     p->unroll = static_cast<int>(env_long("FLEX_U", 0));
     const uint32_t S = 64u / static_cast<uint32_t>(G);      // records per step: rows are padded to it
