@@ -292,7 +292,7 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
     auto flush = [&](uint32_t pos) {
         do {
             const uint32_t dst = __builtin_amdgcn_readlane(my_dst, ti);
-            if (dst & kPartialFlag) {  // wave-uniform
+            if (__builtin_expect((dst & kPartialFlag) != 0, 0)) {  // wave-uniform; the rare case on 1-D plans
                 const float4 r = reduce_full<G>(acc);
                 float *prow = p.partial + static_cast<uint64_t>(dst & ~kPartialFlag) * k;  // uniform
                 if (slot == 0 && col_ok) {
@@ -463,8 +463,12 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
 // STAMP = true is the measuring twin of the product kernel (flex_plan_measure_imbalance; ≙ the reference's per-warp
 // %smid + clock() stamps, flex.cu:27-79): the same code plus, per wave, two reads of the 100 MHz constant clock and one
 // 24-byte record {start, end, XCC id << 32 | HW_ID}.  The product launches (flex_spmm) never use it.
+// amdgpu_waves_per_eu: the wide tiles (G >= 32, U = 8, 32-bit offsets) come out at 76 VGPRs = 6 waves per SIMD unless the
+// allocator is told that a seventh wave is worth a few moves (72 VGPRs, no scratch: checked with `make asm`); the narrow
+// tiles are at 8 waves per SIMD either way, and the variants that would spill under the hint (64-bit row addressing, the
+// FLEX_U=8 experiment) are left alone.
 template <int G, bool OFF32, int U, int WPB, bool STAMP = false>
-__global__ __launch_bounds__(64 * WPB) void spmm_flat_kernel(PlanView p, const float *__restrict__ B,
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(OFF32 && U == (G >= 32 ? 8 : 4) ? 7 : 4))) void spmm_flat_kernel(PlanView p, const float *__restrict__ B,
                                                              float *__restrict__ C) {
     __shared__ uint2 lds_rec[WPB][kWindowRecs];
     const int lane = threadIdx.x & 63;
