@@ -456,8 +456,11 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     // high-degree graphs (reddit: best at >= 256).  Measured on MI355X, DESIGN.md 3.3.
     // (k <= 32, G = 8: a step consumes 8 records, so the same number of steps needs more records per chunk --
     //  flickr k=32 best at 192, ppi 192, yelp 256, pubmed 128; 7-23 % over the k=128 rule)
+    // (round 2, G = 8 again: the upper clamp was 256; amazon shape k=128 9.08 -> 8.87 ms and k=32 2.34 -> 2.26 ms at 512,
+    //  reddit k=32 174 -> 165 us at 512, yelp k=32 131 -> 126 us at 384 (its rule value: 16 x 19.5 = 312); 768-1024 lose
+    //  it again; G = 16 (reddit k=128) is flat from 256 to 512 and keeps 256)
     const long lo_budget = G <= 8 ? 128 : 96;
-    long auto_budget = std::clamp<long>(static_cast<long>((G <= 8 ? 16.0 : 8.0) * avg_deg), lo_budget, 256);
+    long auto_budget = std::clamp<long>(static_cast<long>((G <= 8 ? 16.0 : 8.0) * avg_deg), lo_budget, G <= 8 ? 512 : 256);
     // small inputs: keep at least ~2048 chunks (two waves per SIMD) before growing them (wiki-Vote shape, k=32:
     // 5.5 us at 128-160 records per chunk, 6.3 at 200)
     auto_budget = std::min(auto_budget, std::max<long>(lo_budget, static_cast<long>(A->rowPtr[r1] - A->rowPtr[r0]) / 2048));
@@ -465,16 +468,19 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     const uint32_t row_cost = static_cast<uint32_t>(env_long("FLEX_ROW_COST", 16));
     p->xcd_remap = env_long("FLEX_XCD_REMAP", 1) != 2;  // 2 = off (tuning experiments only)
     p->lds_extra = static_cast<unsigned>(env_long("FLEX_LDS_EXTRA", 1)) & ~15u;  // default 0 (1 -> 0)
-    // The record stream is read once per column tile.  When a launch has SEVERAL tiles (k > 4G) and the stream is large
-    // against the caches (>= 32 MB), non-temporal loads keep one tile's pass over the records from displacing B rows in the
-    // L2s and the Infinity Cache: amazon shape k=128 9.48 -> 9.00 ms, reddit 687 -> 679 us, yelp 524 -> 515 us.  With ONE
-    // tile the same loads cost time instead (they sit on the header -> records -> gathers chain of every chunk and come
-    // back slower): reddit k=32 178 -> 196 us, yelp k=32 130 -> 148 us, flickr k=128 37.9 -> 40.4 us (same box, DESIGN.md
-    // 3.4).  FLEX_REC_NT = 1 / 2 forces them on / off.
+    // The record stream is read once per column tile.  Non-temporal loads keep it from displacing B rows in the L2s and
+    // the Infinity Cache, but they also come back slower and sit on the header -> records -> gathers chain of every chunk.
+    // Measured on MI355X (same box each):
+    //   several tiles (k > 4G), stream >= 32 MB:  amazon shape k=128 9.48 -> 9.00 ms, reddit 687 -> 679 us, yelp 524 -> 515 us
+    //   one tile, stream of 0.1-0.2 GB:           reddit k=32 178 -> 196 us, yelp k=32 130 -> 148 us   (worse)
+    //   one tile, stream of 2.1 GB (8x the Infinity Cache): amazon k=32 2.43 -> 2.29 ms
+    //   small streams:                            flickr k=128 37.9 -> 40.4 us                          (worse)
+    // hence: on for multi-tile launches from 32 MB, for single-tile launches only from 1 GiB.  FLEX_REC_NT = 1 / 2 forces.
     {
         const long nt_env = env_long("FLEX_REC_NT", 0);
         const int ktiles_nt = (k + 4 * G - 1) / (4 * G);
-        p->rec_nt = nt_env == 1 || (nt_env != 2 && ktiles_nt >= 2 && static_cast<uint64_t>(A->rowPtr[r1] - A->rowPtr[r0]) * 8u >= (32u << 20));
+        const uint64_t stream_bytes = static_cast<uint64_t>(A->rowPtr[r1] - A->rowPtr[r0]) * 8u;
+        p->rec_nt = nt_env == 1 || (nt_env != 2 && stream_bytes >= (ktiles_nt >= 2 ? (32ull << 20) : (1ull << 30)));
     }
     p->unroll = static_cast<int>(env_long("FLEX_U", 0));
     const uint32_t S = 64u / static_cast<uint32_t>(G);      // records per step: rows are padded to it

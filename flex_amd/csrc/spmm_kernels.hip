@@ -198,7 +198,10 @@ __device__ __forceinline__ void wait_loads(v4f (&v)[N]) {
                  : "memory");
 }
 
-constexpr int kWindowRecs = 256;  // records staged per wave and window (2 KiB of LDS)
+// records staged per wave and window: 256 (2 KiB of LDS) on the wide tiles, 512 on the G = 8 tile, whose chunk budget goes up to
+// 512 records (plan.cpp) -- one window per chunk there; measured with the budget
+template <int G>
+constexpr int kWindowRecs = G <= 8 ? 512 : 256;
 
 [[maybe_unused]] __device__ __forceinline__ uint32_t xcc_id() {
     uint32_t x;
@@ -238,22 +241,31 @@ __device__ __forceinline__ uint2 load_rec(const uint2 *ptr) {
     }
 }
 
-template <bool NT>
+template <bool NT, int LOADS>
+__device__ __forceinline__ void stage_n(uint2 *my_lds, const uint2 *__restrict__ rec, uint32_t wz, uint32_t wn, int lane) {
+    uint2 r[LOADS];
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) r[i] = load_rec<NT>(rec + wz + min(static_cast<uint32_t>(i * 64 + lane), wn - 1));
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) my_lds[i * 64 + lane] = r[i];
+}
+
+template <bool NT, int G>
 __device__ __forceinline__ void stage_window_t(uint2 *my_lds, const uint2 *__restrict__ rec, uint32_t wz, uint32_t wn, int lane) {
     if (wn <= 64) {
-        my_lds[lane] = load_rec<NT>(rec + wz + min(static_cast<uint32_t>(lane), wn - 1));
+        stage_n<NT, 1>(my_lds, rec, wz, wn, lane);
+    } else if constexpr (kWindowRecs<G> > 256) {
+        if (wn <= 256) stage_n<NT, 4>(my_lds, rec, wz, wn, lane);
+        else stage_n<NT, kWindowRecs<G> / 64>(my_lds, rec, wz, wn, lane);
     } else {
-        uint2 r[kWindowRecs / 64];
-#pragma unroll
-        for (int i = 0; i < kWindowRecs / 64; ++i) r[i] = load_rec<NT>(rec + wz + min(static_cast<uint32_t>(i * 64 + lane), wn - 1));
-#pragma unroll
-        for (int i = 0; i < kWindowRecs / 64; ++i) my_lds[i * 64 + lane] = r[i];
+        stage_n<NT, 4>(my_lds, rec, wz, wn, lane);
     }
 }
 
+template <int G>
 __device__ __forceinline__ void stage_window(uint2 *my_lds, const uint2 *__restrict__ rec, uint32_t wz, uint32_t wn, int lane, bool nt) {
-    if (nt) stage_window_t<true>(my_lds, rec, wz, wn, lane);  // wave-uniform
-    else stage_window_t<false>(my_lds, rec, wz, wn, lane);
+    if (nt) stage_window_t<true, G>(my_lds, rec, wz, wn, lane);  // wave-uniform
+    else stage_window_t<false, G>(my_lds, rec, wz, wn, lane);
 }
 
 // All the work of one chunk once its header {first task, #tasks, first record, end record} and its
@@ -322,10 +334,10 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
     if (row_end == zb) flush(zb);  // leading empty rows
 
     uint32_t pos = zb;  // stream position after the steps consumed so far
-    for (uint32_t wz = zb; wz < ze; wz += kWindowRecs) {
-        const uint32_t wn = min(static_cast<uint32_t>(kWindowRecs), ze - wz);
+    for (uint32_t wz = zb; wz < ze; wz += kWindowRecs<G>) {
+        const uint32_t wn = min(static_cast<uint32_t>(kWindowRecs<G>), ze - wz);
         // stage this window's records: coalesced 512-B loads, one ds_write_b64 per lane and load
-        stage_window(my_lds, rec, wz, wn, lane, p.rec_nt != 0);
+        stage_window<G>(my_lds, rec, wz, wn, lane, p.rec_nt != 0);
         FLEX_STAMP(1);  // records -> LDS
 #ifdef FLEX_ABL_STAGEONLY  // timing-only ablation: header, descriptors and records fetched, then leave
         if (p.k > 0) {
@@ -470,7 +482,7 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
 template <int G, bool OFF32, int U, int WPB, bool STAMP = false>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(OFF32 && U == (G >= 32 ? 8 : 4) ? 7 : 4))) void spmm_flat_kernel(PlanView p, const float *__restrict__ B,
                                                              float *__restrict__ C) {
-    __shared__ uint2 lds_rec[WPB][kWindowRecs];
+    __shared__ uint2 lds_rec[WPB][kWindowRecs<G>];
     const int lane = threadIdx.x & 63;
     const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t cpx = gridDim.x / kXcds;  // gridDim.x % 8 == 0

@@ -306,7 +306,7 @@ def test_in_launch_split_row_reduction_is_stable_under_repetition():
     B = dev(Bn)
     p = Plan(a, k)
     info = p.info()
-    assert info["n_split_rows"] >= 1900 and info["n_partials"] > 10000
+    assert info["n_split_rows"] >= 1900 and info["n_partials"] > 5000
     ref = p(B).clone()
     torch.cuda.synchronize()
     assert_matches_oracle(a, Bn, ref.cpu().numpy(), nthreads=8)
