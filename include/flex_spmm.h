@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define FLEX_ABI_VERSION 1
+#define FLEX_ABI_VERSION 2 /* 2: flex_plan_info / flex_plan_stats grew (2-D, MFMA tiles, records, detector report); flex_plan_desc flag FLEX_PLAN_ROW_RANGE; flex_order_rabbit, flex_plan_measure_imbalance */
 
 typedef enum flex_status {
     FLEX_OK = 0,

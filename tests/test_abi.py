@@ -19,7 +19,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     L = ctypes.CDLL(flex_amd.lib_path())
     for s in declared:
         assert hasattr(L, s), s
-    assert flex_amd.lib().flex_abi_version() == 1
+    assert flex_amd.lib().flex_abi_version() == 2
 
 
 @pytest.mark.parametrize("header,lib", [("flex_spmm.h", "libflex_spmm.so"), ("flex_vendor.h", "libflex_vendor.so"),
