@@ -122,6 +122,7 @@ struct Clusterer {
     void run(int max_rounds) {
         if (M <= 0) return;
         const int nthr = host_threads();
+        WorkerPool pool(nthr);  // one set of threads for the few hundred small parallel sections below
         std::vector<std::vector<float>> acc(static_cast<size_t>(nthr));
         std::vector<std::vector<uint32_t>> touched(static_cast<size_t>(nthr));
         std::vector<uint32_t> cur(static_cast<size_t>(n)), next, pick(static_cast<size_t>(n));
@@ -136,7 +137,22 @@ struct Clusterer {
         auto secs = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
         for (int round = 1; round <= max_rounds && !cur.empty(); ++round) {
             const auto ts0 = now();
-            std::stable_sort(cur.begin(), cur.end(), [&](uint32_t a, uint32_t b) { return cdeg[a] < cdeg[b]; });
+            // lowest community degree first, ties in list order.  Degrees are sums of integer degrees: when their range is
+            // small against the list (round 1: every vertex, degrees < n) a stable counting sort replaces the comparison sort
+            {
+                double dmax = 0;
+                for (uint32_t u : cur) dmax = std::max(dmax, cdeg[u]);
+                if (cur.size() >= (1u << 16) && dmax < 4.0 * static_cast<double>(cur.size())) {
+                    const size_t nb = static_cast<size_t>(dmax) + 2;
+                    std::vector<uint32_t> count(nb, 0u), sorted(cur.size());
+                    for (uint32_t u : cur) ++count[static_cast<size_t>(cdeg[u]) + 1];
+                    for (size_t i = 1; i < nb; ++i) count[i] += count[i - 1];
+                    for (uint32_t u : cur) sorted[count[static_cast<size_t>(cdeg[u])]++] = u;
+                    cur.swap(sorted);
+                } else {
+                    std::stable_sort(cur.begin(), cur.end(), [&](uint32_t a, uint32_t b) { return cdeg[a] < cdeg[b]; });
+                }
+            }
             t_sort += secs(ts0, now());
             next.clear();
             moved.clear();
@@ -147,7 +163,7 @@ struct Clusterer {
                 // A: proposals of this batch, from the state left by the batches before it
                 const auto ta0 = now();
                 constexpr int64_t kBlk = 64;
-                parallel_chunks_tid((b1 - b0 + kBlk - 1) / kBlk, [&](int64_t b, int tid) {
+                pool.run((b1 - b0 + kBlk - 1) / kBlk, [&](int64_t b, int tid) {
                     if (acc[tid].empty()) acc[tid].assign(static_cast<size_t>(n), 0.f);
                     for (int64_t i = b0 + b * kBlk; i < std::min(b1, b0 + (b + 1) * kBlk); ++i) {
                         const uint32_t u = cur[i];

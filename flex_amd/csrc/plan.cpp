@@ -38,9 +38,14 @@ int validate_csr(const flex_csr *A) {
     for (int32_t r = 0; r < A->m; ++r)
         if (A->rowPtr[r] > A->rowPtr[r + 1]) return FLEX_ERR_INVALID;
     const uint32_t n = static_cast<uint32_t>(A->n);
-    for (int64_t e = 0; e < A->nnz; ++e)
-        if (A->col[e] >= n) return FLEX_ERR_INVALID;
-    return FLEX_OK;
+    constexpr int64_t kBlk = 1 << 20;
+    std::atomic<int> bad{0};
+    parallel_chunks((A->nnz + kBlk - 1) / kBlk, [&](int64_t b) {
+        uint32_t worst = 0;
+        for (int64_t e = b * kBlk; e < std::min<int64_t>(A->nnz, (b + 1) * kBlk); ++e) worst = std::max(worst, A->col[e]);
+        if (worst >= n) bad.store(1);
+    });
+    return bad.load() ? FLEX_ERR_INVALID : FLEX_OK;
 }
 
 static long env_long(const char *name, long dflt) {
