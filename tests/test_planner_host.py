@@ -1,0 +1,133 @@
+"""The planner's host logic WITHOUT a GPU: every kind of plan is created through the C ABI of a host-simulated build
+(tests/hostsim: same sources, "device memory" = malloc, no kernels) and its image is verified by flex_plan_self_check --
+chunks tile the tasks, tasks tile the records, every C row has exactly one writer, pieces name their row, the dense-tile
+directory is consistent -- for the 1-D schedule, the 2-D column-panel schedule, the MFMA dense-tile route, mapped plans,
+row shards, padded storage, every column-tile width.  flex_spmm must refuse (no CPU compute path exists)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import flex_amd
+from flex_amd import binding
+from util import random_csr
+
+hostsim = pytest.importorskip("hostsim")
+
+
+@pytest.fixture(scope="module")
+def sim():
+    """binding.py pointed at the host-simulated library for the duration of this module."""
+    so = os.environ.get("FLEX_HOSTSIM_LIB") or hostsim.build()
+    old_so, old_lib = binding._SO, binding._lib
+    binding._SO, binding._lib = so, None
+    yield binding.lib()
+    binding._SO, binding._lib = old_so, old_lib
+
+
+def block_dense(n, block, fill, noise, seed):
+    rng = np.random.default_rng(seed)
+    nb = n // block
+    b, r, c = np.nonzero(rng.random((nb, block, block)) < fill)
+    rows = np.concatenate([b * block + r, np.repeat(np.arange(nb * block), noise)])
+    cols = np.concatenate([b * block + c, rng.integers(0, nb * block, size=nb * block * noise)])
+    key = np.unique(rows.astype(np.int64) * (nb * block) + cols)
+    r, c = key // (nb * block), key % (nb * block)
+    rp = np.zeros(nb * block + 1, dtype=np.int64)
+    np.cumsum(np.bincount(r, minlength=nb * block), out=rp[1:])
+    return flex_amd.HostCsr(rp.astype(np.uint32), c.astype(np.uint32), rng.uniform(-1, 1, len(c)).astype(np.float32), n=nb * block)
+
+
+def test_hostsim_cannot_compute(sim):
+    a = random_csr(200, 200, 5, seed=1)
+    p = flex_amd.Plan(a, 32)
+    p.self_check()
+    with pytest.raises(flex_amd.FlexError, match="not supported"):
+        p.spmm(0x1000, 0x2000, 0)  # no kernels in this build: the launch is refused, nothing is computed
+    assert not hasattr(sim, "flex_spmm_host")
+
+
+@pytest.mark.parametrize("k", [1, 7, 32, 100, 128, 256, 512])
+@pytest.mark.parametrize("order", [flex_amd.FLEX_ORDER_NATURAL, flex_amd.FLEX_ORDER_RCM, flex_amd.FLEX_ORDER_CLUSTER, flex_amd.FLEX_ORDER_GORDER])
+def test_one_d_plans_are_partitions(sim, k, order):
+    a = flex_amd.synth_graph(n=5000, nnz=5000 + 2 * 60000, community=100, p_in=0.55, p_near=0.25, seed=3)
+    p = flex_amd.Plan(a, k, order=order | flex_amd.FLEX_PLAN_STATS)
+    p.self_check()
+    info, st = p.info(), p.stats()
+    assert info["nnz"] == a.nnz and info["n_chunks"] <= info["n_slots"] and st["records"] + info["tile_nnz"] >= a.nnz
+    assert info["n_records"] == st["records"]
+
+
+def test_ragged_shapes_shards_maps_and_strides(sim):
+    a = random_csr(4000, 4000, 25, seed=7, long_rows={3: 3900, 2000: 1500, 3999: 700}, empty_frac=0.2)
+    for k in (32, 128):
+        flex_amd.Plan(a, k).self_check()
+        flex_amd.Plan(a, k, ldb=k + 32, ldc=k + 4).self_check()
+    rank = flex_amd.order_cluster(a)
+    vo, ap = flex_amd.perm_csr(a, rank)
+    flex_amd.Plan(ap, 128, vo_mp=vo).self_check()
+    bounds = flex_amd.shard_rows(ap, 128, 5)
+    total = 0
+    for i in range(5):
+        p = flex_amd.Plan(ap, 128, rows=(bounds[i], bounds[i + 1]), col_map=vo)
+        p.self_check()
+        total += p.info()["nnz"]
+    assert total == a.nnz
+    pe = flex_amd.Plan(ap, 64, rows=(0, 0), col_map=vo, ldb=96, ldc=64)  # an empty shard through the descriptor form
+    assert pe.info()["m"] == 0
+    rect = random_csr(900, 5000, 40, seed=8, long_rows={5: 4000})
+    flex_amd.Plan(rect, 128).self_check()
+    empty = flex_amd.HostCsr(np.zeros(6, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.float32), n=5)
+    flex_amd.Plan(empty, 32).self_check()
+
+
+@pytest.mark.parametrize("lanes,k", [(8, 32), (8, 128), (16, 128), (32, 128), (64, 256)])
+def test_two_d_plans_are_partitions(sim, monkeypatch, lanes, k):
+    a = flex_amd.synth_graph(n=6000, nnz=6000 + 2 * 90000, community=200, p_in=0.55, p_near=0.3, seed=5)
+    monkeypatch.setenv("FLEX_2D", "1")
+    monkeypatch.setenv("FLEX_PANEL_KB", "32")
+    monkeypatch.setenv("FLEX_SEG_MIN", "2")
+    monkeypatch.setenv("FLEX_LANES", str(lanes))
+    for order in (flex_amd.FLEX_ORDER_NATURAL, flex_amd.FLEX_ORDER_CLUSTER):
+        p = flex_amd.Plan(a, k, order=order)
+        info = p.info()
+        assert info["two_d"] == 1 and info["lanes_per_nz"] == lanes and info["n_split_rows"] > a.m // 2
+        p.self_check()
+
+
+def test_dense_tile_route_is_consistent(sim, monkeypatch):
+    a = block_dense(6400, 64, 0.85, 5, seed=2)
+    p = flex_amd.Plan(a, 128, order=flex_amd.FLEX_ORDER_NATURAL | flex_amd.FLEX_PLAN_STATS)
+    info, st = p.info(), p.stats()
+    assert info["n_tiles"] == 2 * 2 * (6400 // 64) and info["tile_nnz"] > 0.8 * a.nnz  # every 64-block = four 32x32 tiles
+    assert abs(st["mfma_nnz_pct"] - 100.0 * info["tile_nnz"] / a.nnz) < 1e-9 and st["tile_nnz_pct_50"] >= st["mfma_nnz_pct"] - 1e-9
+    assert st["records"] + info["tile_nnz"] >= a.nnz
+    p.self_check()
+    monkeypatch.setenv("FLEX_MFMA", "2")
+    p2 = flex_amd.Plan(a, 128, order=flex_amd.FLEX_PLAN_STATS)
+    assert p2.info()["n_tiles"] == 0 and p2.stats()["tile_nnz_pct_50"] == st["tile_nnz_pct_50"]  # the report does not depend on the route
+    monkeypatch.setenv("FLEX_MFMA", "1")
+    monkeypatch.setenv("FLEX_MFMA_FILL", "25")
+    # a tile row that hangs over the end of the matrix, a shard, and a 2-D plan on top of the route
+    odd = block_dense(1000, 40, 0.9, 3, seed=4)
+    flex_amd.Plan(odd, 64).self_check()
+    flex_amd.Plan(odd, 64, rows=(100, 777)).self_check()
+    monkeypatch.setenv("FLEX_2D", "1")
+    monkeypatch.setenv("FLEX_PANEL_KB", "16")
+    p3 = flex_amd.Plan(a, 128)
+    assert p3.info()["two_d"] == 1 and p3.info()["n_tiles"] > 0
+    p3.self_check()
+
+
+def test_planner_result_does_not_depend_on_the_thread_count(sim, monkeypatch):
+    a = flex_amd.synth_graph(n=20000, nnz=20000 + 2 * 400000, community=256, p_in=0.6, p_near=0.25, seed=9)
+    monkeypatch.setenv("FLEX_2D", "1")
+    shapes = []
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("FLEX_HOST_THREADS", threads)
+        p = flex_amd.Plan(a, 128, order=flex_amd.FLEX_ORDER_CLUSTER | flex_amd.FLEX_PLAN_STATS)
+        p.self_check()
+        i, s = p.info(), p.stats()
+        shapes.append((i["n_tasks"], i["n_chunks"], i["n_slots"], i["n_partials"], i["n_records"], s["cols_wave"], s["cols_xcd"], s["chunk_rec_max"]))
+    assert shapes[0] == shapes[1] == shapes[2]
