@@ -11,3 +11,6 @@ for cfg in "pubmed 32" "pubmed 128" "flickr 32" "flickr 128" "yelp 32" "yelp 128
   steps=200; [ $1 = reddit ] && steps=50; [ $1 = yelp ] && steps=50; [ $1 = amazon ] && steps=10
   timeout -k 10 600 python bench.py --workload $1 --k $2 --steps $steps --warmup 5 --no-cpu-baseline --no-copy-probe >> $out 2>> ${out%.jsonl}.err || echo "{\"failed\": \"$cfg\"}" >> $out
 done
+# BASELINE configs[2] names RCM-reordered rows for the Reddit shape: the same protocol with RCM as the schedule (the community
+# schedule above is what the engine picks by itself)
+timeout -k 10 600 python bench.py --workload reddit --k 128 --order rcm --steps 50 --warmup 5 --no-cpu-baseline --no-copy-probe >> $out 2>> ${out%.jsonl}.err || echo "{\"failed\": \"reddit 128 rcm\"}" >> $out

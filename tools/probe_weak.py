@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import flex_amd
 name = sys.argv[1] if len(sys.argv) > 1 else "flickr"
 strong = len(sys.argv) > 2 and sys.argv[2] == "strong"  # fixed graph, rows/N per GPU (the north_star's Amazon run)
-k = 128
+k = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 a1 = flex_amd.synth_graph(name) if strong else None
 for N in (1, 2, 4, 8):
     a = a1 if strong else flex_amd.synth_graph(name, scale=N)
@@ -31,6 +31,6 @@ for N in (1, 2, 4, 8):
             best = min(best, e0.elapsed_time(e1) / 50 * 1e3)
         ts.append((r, rows, nnz, best))
     worst = max(t[3] for t in ts)
-    print(f"{name} {'strong /' if strong else 'x'}{N}: n={a.n} nnz={a.nnz} B={a.n*k*4/1e6:.0f} MB; shards " +
+    print(f"{name} k={k} {'strong /' if strong else 'x'}{N}: n={a.n} nnz={a.nnz} B={a.n*k*4/1e6:.0f} MB; shards " +
           ", ".join(f"r{r}: {rows} rows {nnz} nnz {t:.1f}us" for r, rows, nnz, t in ts) +
           f"  -> predicted aggregate {2*a.nnz*k/worst/1e3:.0f} GFLOPS")
