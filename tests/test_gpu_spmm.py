@@ -357,8 +357,10 @@ def test_bench_json_contract():
     assert j["hipsparse"]["value"] > 0
 
 
-def test_b_larger_than_4GiB_uses_64bit_row_addressing():
-    """n*k*4 > 2^32: records carry column ids instead of 32-bit byte offsets (OFF32 = false kernels)."""
+@pytest.mark.parametrize("dense_block", [False, True])
+def test_b_larger_than_4GiB_uses_64bit_row_addressing(monkeypatch, dense_block):
+    """n*k*4 > 2^32: records carry column ids instead of 32-bit byte offsets (OFF32 = false kernels); with a dense block of A
+    at the far end of the column range the MFMA tile kernel's 64-bit row addressing is exercised too."""
     m, n, k = 1500, 2_200_000, 512
     free, _ = torch.cuda.mem_get_info()
     if free < 12 * (1 << 30):
@@ -366,16 +368,23 @@ def test_b_larger_than_4GiB_uses_64bit_row_addressing():
     rng = np.random.default_rng(123)
     deg = rng.integers(0, 40, size=m)
     deg[7] = 3000  # one split row
+    if dense_block:
+        deg[64:128] = 60  # rows 64..127 x the last 64 columns: four 32x32 tiles of fill ~0.9
     rp = np.zeros(m + 1, dtype=np.int64)
     np.cumsum(deg, out=rp[1:])
     col = rng.integers(0, n, size=rp[-1]).astype(np.uint32)
     col[:64] = n - 1 - np.arange(64)  # make sure the top of the address range is touched
+    if dense_block:
+        monkeypatch.setenv("FLEX_MFMA", "1")
+        for r in range(64, 128):
+            col[rp[r]:rp[r + 1]] = np.sort(rng.choice(np.arange(n - 64, n), size=60, replace=False)).astype(np.uint32)
     a = flex_amd.HostCsr(rp.astype(np.uint32), col, rng.uniform(-1, 1, rp[-1]).astype(np.float32), n=n)
     i = torch.arange(n, device="cuda", dtype=torch.float32).unsqueeze(1)
     j = torch.arange(k, device="cuda", dtype=torch.float32).unsqueeze(0)
     B = torch.sin(i * 0.37 + j * 0.11)  # cheap, non-trivial, reproducible on the host from the device copy
     assert B.numel() * 4 > (1 << 32)
     p = Plan(a, k)
+    assert (p.info()["n_tiles"] >= 4) == dense_block
     C = p(B)
     torch.cuda.synchronize()
     used = np.unique(col)
@@ -762,6 +771,22 @@ def test_two_d_with_hubs_empty_rows_shards_and_strides(monkeypatch):
         ps.self_check()
         got[sh.original_rows()] = run_plan(ps, Bg)
     assert oracle.rescheck(gold, got, g.rowPtr)[0] == 0
+
+
+def test_two_d_schedule_on_top_of_the_dense_tile_route(monkeypatch):
+    """Both plan features at once, executed: dense diagonal blocks go to the MFMA kernel, the rest is walked panel by panel."""
+    a = block_dense_graph(6400, 64, 0.85, 12, seed=11)
+    B = random_B(a.n, 128, 2)
+    monkeypatch.setenv("FLEX_2D", "1")
+    monkeypatch.setenv("FLEX_PANEL_KB", "64")
+    monkeypatch.setenv("FLEX_SEG_MIN", "2")
+    p = Plan(a, 128)
+    info = p.info()
+    assert info["two_d"] == 1 and info["n_tiles"] > 300 and info["n_partials"] > 0
+    p.self_check()
+    C1 = run_plan(p, B)
+    assert_matches_oracle(a, B, C1)
+    assert np.array_equal(C1, run_plan(p, B))
 
 
 def test_two_d_reduction_is_stable_under_repetition(monkeypatch):
