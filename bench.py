@@ -257,6 +257,12 @@ def main():
                          "gather_rate_GBps": round(gather_demand / (kern_ms * 1e-3) / 1e9, 1),
                          "l2_gather_rate_measured_GBps": [16800, 18800]},
         }
+        # the two terms of DESIGN.md 3.4's roof model for this launch: gather demand at the chip's measured L2 gather rate
+        # (18.6 TB/s, the upper half of the guide's 16.8-18.8) and -- when the committed PMC figure applies -- L2-miss traffic at the
+        # 6.3 TB/s the fabric delivers; the launch time is about the larger of the two
+        out["roofline"]["model_gather_floor_ms"] = round(gather_demand / 18.6e12 * 1e3, 6)
+        if out["roofline"]["traffic"] is not None:
+            out["roofline"]["model_fabric_ms"] = round(out["roofline"]["traffic"] / 6.3e12 * 1e3, 6)
         if per_rank is not None:
             nnzs = [r[2] for r in per_rank]
             out["config"]["per_rank_ms"] = [round(r[1] / args.steps, 6) for r in per_rank]        # HIP events, per step
