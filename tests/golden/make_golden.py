@@ -2,10 +2,10 @@
 """Regenerates tests/golden/golden.npz from the CPU oracle.
 
 The reference cannot be built in this image ("Oracle"), so these
-vectors come from the oracle AFTER it has been pinned against the figures the
+vectors come from the oracle AFTER it has reproduced the three numbers the
 survey recorded from the reference's host half (cpuX prefix,
 sum(C)=666.878358 on pubmed k=32, RCM bandwidth 19482->6241) -- this script
-asserts those pins before writing anything.  The two .csv files next to this
+asserts those numbers before writing anything (survey-recorded, not reference-held: they pin nothing).  The two .csv files next to this
 script are the reference's own data fixtures (data/pubmed.csv, data/a_mat.csv).
 
 Run from the repo root:  python tests/golden/make_golden.py
@@ -37,7 +37,7 @@ def main():
     for k in (32, 128):
         B = oracle.gen_B(p.n, k)
         Cm = oracle.spmm(p.rowPtr, p.col, p.vals, B)
-        if k == 32:  # pins recorded from the reference's host half
+        if k == 32:  # number SURVEY.md 8(c) recorded from a probe of the reference's host half (not a reference-held fixture)
             assert np.allclose(B.ravel()[:4], [0.680375, -0.211234, 0.566198, 0.59688], atol=5e-7)
             assert abs(float(Cm.astype(np.float64).sum()) - 666.878358) < 5e-7
         idx = np.sort(rng.choice(Cm.size, size=512, replace=False))

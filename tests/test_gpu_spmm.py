@@ -56,7 +56,7 @@ def test_pubmed_vs_oracle_and_golden(golden, k, order):
     g = golden[f"pubmed_k{k}_C_at_idx"]
     assert np.all(np.abs(C.ravel()[idx] - g) <= 4 * np.finfo(np.float32).eps * deg * np.maximum(1, np.abs(g)))
     assert abs(C.astype(np.float64).sum() - float(golden[f"pubmed_k{k}_C_sum"])) < 1e-2
-    if k == 32:  # the reference's own figure
+    if k == 32:  # the number SURVEY.md 8(c) recorded from its probe of the reference's host half
         assert abs(C.astype(np.float64).sum() - 666.878358) < 1e-2
 
 

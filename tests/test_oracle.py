@@ -1,4 +1,5 @@
-"""CPU tests of the oracle itself: pins from the reference, golden vectors, scipy cross-check."""
+"""CPU tests of the oracle itself: the survey-recorded numbers (not reference-held fixtures: parity stays unpinned),
+the regression vectors, scipy / literal-loop cross-checks."""
 import os
 
 import numpy as np
