@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/sweep_gen.py [out.json] -- sensitivity of the Reddit-shape measurements to the stand-in generator's structure
+"""tools/sweep_gen.py [out.json] [workload] -- sensitivity of the Reddit-shape (or, second argument, Amazon-shape) measurements to the stand-in generator's structure
 parameters (share of uniformly random edges, community size, width of the "near" ring).  Every point: the preset's n, nnz and
 degree law, k = 128, cluster schedule; 2 warm-up + 5 timed launches (always 7 dispatches of spmm_flat_kernel per point, so
 that a rocprofv3 --pmc pass of this same script can be cut into points by dispatch order: tools/sweep_gen_pmc.py)."""
@@ -19,14 +19,19 @@ POINTS = [  # (label, community, p_in, p_near, window)
     ("community 512", 512, 0.60, 0.25, 8), ("community 8192", 8192, 0.60, 0.25, 8), ("near ring +-2", 2048, 0.60, 0.25, 2),
     ("near ring +-32", 2048, 0.60, 0.25, 32),
 ]
-sp = flex_amd.synth_preset("reddit")
+WL = sys.argv[2] if len(sys.argv) > 2 else "reddit"
+if WL == "amazon":  # the headline shape: fewer points (each is 264 M nonzeros), its preset community is 4096
+    POINTS = [("random 0.00", 4096, 0.75, 0.25, 8), ("random 0.15 (preset)", 4096, 0.60, 0.25, 8), ("random 0.40", 4096, 0.35, 0.25, 8),
+              ("community 1024", 1024, 0.60, 0.25, 8), ("community 16384", 16384, 0.60, 0.25, 8), ("near ring +-2", 4096, 0.60, 0.25, 2)]
+sp = flex_amd.synth_preset(WL)
 res = []
 for label, comm, p_in, p_near, win in POINTS:
     a = flex_amd.synth_graph(n=sp.n, nnz=sp.nnz, alpha=sp.alpha, community=comm, p_in=p_in, p_near=p_near, near_window=win,
-                             shuffle=True, gcn_norm=True, seed=sp.seed)
+                             shuffle=True, gcn_norm=bool(sp.gcn_norm), seed=sp.seed)
     B = torch.rand((a.n, K), device="cuda") * 2 - 1
     C = torch.empty((a.m, K), device="cuda")
     p = flex_amd.Plan(a, K, order=flex_amd.FLEX_ORDER_CLUSTER | flex_amd.FLEX_PLAN_STATS)
+    del a.col, a.vals  # the plan has copied what it needs
     s = torch.cuda.current_stream().cuda_stream
     for _ in range(2):
         p.spmm(B.data_ptr(), C.data_ptr(), s)
