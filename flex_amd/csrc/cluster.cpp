@@ -36,12 +36,13 @@ struct Clusterer {
     using Adj = std::vector<std::pair<uint32_t, float>>;
     std::vector<Adj> adj;                                          // a community's adjacency as of its last compaction
     std::vector<std::vector<Adj>> segs;                           // + the lists of the communities it has absorbed since (moved, not copied)
-    std::vector<uint8_t> raw;                                     // adjacency still lives in the CSR
+    std::vector<uint8_t> raw;                                     // own adjacency still lives in the CSR (never copied out while it does)
+    std::vector<std::vector<uint32_t>> rawm;                      // + the vertices absorbed in that state: their CSR rows are read in place
     std::vector<std::vector<uint32_t>> children;                  // merge forest
     double M = 0;                                                 // total degree (2m)
 
     Clusterer(int64_t n_, const uint32_t *rp, const uint32_t *c)
-        : n(n_), rowPtr(rp), col(c), parent(n_), cdeg(n_, 0.0), adj(n_), segs(n_), raw(n_, 1), children(n_) {
+        : n(n_), rowPtr(rp), col(c), parent(n_), cdeg(n_, 0.0), adj(n_), segs(n_), raw(n_, 1), rawm(n_), children(n_) {
         std::iota(parent.begin(), parent.end(), 0u);
         constexpr int64_t kBlk = 1 << 14;
         const int64_t nblk = (n + kBlk - 1) / kBlk;
@@ -79,17 +80,26 @@ struct Clusterer {
             if (acc[r] == 0.f) touched.push_back(r);
             acc[r] += w;  // weights are edge counts: exact in fp32, so the order the neighbours are met in does not matter
         };
-        if (raw[u]) {
+        // (a 16 KB per-thread hash table for the small communities instead of the dense array of n floats was tried:
+        //  round 1 of the Amazon shape 1.15 -> 1.4 s on 8 cores -- the dense array's misses overlap, the probing does not)
+        // a vertex that has absorbed nothing keeps reading its CSR row: writing every row out as a list in round 1 and
+        // reading it back in round 2 was 2 x 8 B per nonzero of first-touched heap (0.6 s of a cold Amazon-size plan)
+        const bool leaf = raw[u] && rawm[u].empty() && segs[u].empty();
+        if (raw[u])
             for (uint32_t e = rowPtr[u]; e < rowPtr[u + 1]; ++e) add(col[e], 1.f);
-            raw[u] = 0;
-        }
+        for (uint32_t m : rawm[u])
+            for (uint32_t e = rowPtr[m]; e < rowPtr[m + 1]; ++e) add(col[e], 1.f);
         for (const auto &vw : adj[u]) add(vw.first, vw.second);
         for (const Adj &sg : segs[u])
             for (const auto &vw : sg) add(vw.first, vw.second);
-        std::vector<Adj>().swap(segs[u]);
         auto &list = adj[u];
-        list.clear();
-        list.reserve(touched.size());
+        if (!leaf) {
+            raw[u] = 0;
+            std::vector<uint32_t>().swap(rawm[u]);
+            std::vector<Adj>().swap(segs[u]);
+            list.clear();
+            list.reserve(touched.size());
+        }
         uint32_t best = u;
         double best_gain = 0.0;
         *w_best = 0.f;
@@ -97,7 +107,7 @@ struct Clusterer {
         for (uint32_t r : touched) {
             const float w = acc[r];
             acc[r] = 0.f;
-            list.emplace_back(r, w);
+            if (!leaf) list.emplace_back(r, w);
             const double gain = static_cast<double>(w) - cdeg[r] * du_over_M;  // ~ delta modularity * M
             // ties go to the smaller community id, whatever order the neighbours were met in
             if (gain > best_gain || (gain == best_gain && gain > 0.0 && r < best)) {
@@ -162,7 +172,8 @@ struct Clusterer {
                 const int64_t b1 = std::min(ncur, b0 + batch);
                 // A: proposals of this batch, from the state left by the batches before it
                 const auto ta0 = now();
-                constexpr int64_t kBlk = 64;
+                // late rounds: a few hundred communities that hold the whole graph between them -- one per work item
+                const int64_t kBlk = b1 - b0 >= 4096 ? 64 : 1;
                 pool.run((b1 - b0 + kBlk - 1) / kBlk, [&](int64_t b, int tid) {
                     if (acc[tid].empty()) acc[tid].assign(static_cast<size_t>(n), 0.f);
                     for (int64_t i = b0 + b * kBlk; i < std::min(b1, b0 + (b + 1) * kBlk); ++i) {
@@ -203,11 +214,17 @@ struct Clusterer {
                 const auto tc0 = now();
                 t_b += secs(tb0, tc0);
                 for (const auto &ru : moved) {
-                    auto &dst = segs[ru.first];
-                    dst.push_back(std::move(adj[ru.second]));
-                    for (Adj &sg : segs[ru.second]) dst.push_back(std::move(sg));
-                    Adj().swap(adj[ru.second]);
-                    std::vector<Adj>().swap(segs[ru.second]);
+                    const uint32_t r = ru.first, u = ru.second;
+                    if (raw[u]) rawm[r].push_back(u);
+                    if (!rawm[u].empty()) {
+                        rawm[r].insert(rawm[r].end(), rawm[u].begin(), rawm[u].end());
+                        std::vector<uint32_t>().swap(rawm[u]);
+                    }
+                    auto &dst = segs[r];
+                    if (!adj[u].empty()) dst.push_back(std::move(adj[u]));
+                    for (Adj &sg : segs[u]) dst.push_back(std::move(sg));
+                    Adj().swap(adj[u]);
+                    std::vector<Adj>().swap(segs[u]);
                 }
                 moved.clear();
                 t_c += secs(tc0, now());
