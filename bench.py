@@ -354,7 +354,7 @@ def dry_run_tail(args, a, k, rank, world, shard, t_gen, t_plan):
         dist.destroy_process_group()
 
 
-TRAFFIC_SOURCES = ("spmm_kernels.hip", "plan.cpp", "internal.h", "cluster.cpp", "synth.cpp")
+TRAFFIC_SOURCES = ("spmm_kernels.hip", "plan.h", "plan.cpp", "plan_build.cpp", "dense_tiles.cpp", "internal.h", "cluster.cpp", "synth.cpp")
 
 
 def traffic_source_hash():

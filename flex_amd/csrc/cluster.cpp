@@ -12,7 +12,7 @@
 // allocation), which is what makes Amazon-size inputs (2.6e8 nnz) practical.
 //
 // In this engine an ordering is a SCHEDULE (which rows a wave / an XCD works on
-// next), never a data permutation: see plan.cpp.
+// next), never a data permutation: see plan_build.cpp.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>

@@ -1,0 +1,105 @@
+// plan.h -- the plan object and what the planner's translation units share (host side only).
+//
+//   plan.cpp          life cycle and launch half of the C ABI (create*, flex_spmm, destroy, info), the autotuner
+//   plan_build.cpp    PlanBuilder: CSR rows -> schedule -> pieces -> tasks / chunks / records -> device image
+//   dense_tiles.cpp   the block-density detector and the dense-tile store of the MFMA route
+//   plan_check.cpp    what is read back from a finished plan: self-check, statistics, measured imbalance
+#pragma once
+#include <cstdlib>
+#include <vector>
+
+#include "internal.h"
+
+struct flex_plan {
+    int32_t m = 0, n = 0, k = 0, device = 0;
+    int32_t ldb = 0, ldc = 0;  // row strides of B and C in floats (== k unless flex_plan_create_ld)
+    int64_t nnz = 0;
+    int lanes_per_nz = 0;
+    bool off32 = false;
+    bool xcd_remap = true;
+    unsigned lds_extra = 0;
+    bool rec_nt = false;
+    int unroll = 0;
+    uint64_t *trace = nullptr;
+    unsigned order = 0;
+    uint2 *d_rec = nullptr;
+    uint32_t *d_t_beg = nullptr, *d_t_dst = nullptr;
+    uint2 *d_t_aux = nullptr;
+    uint4 *d_chunk = nullptr;
+    float *d_partial = nullptr;
+    flex::SplitRow *d_split = nullptr;
+    uint32_t *d_split_cnt = nullptr;
+    bool fused_fixup = false;
+    bool two_d = false;  // rows cut by column panel (phases), not only by length
+    // dense 32x32 tiles routed to the MFMA kernel (tile_kernels.hip)
+    float *d_tile_a = nullptr;
+    uint32_t *d_tile_boff = nullptr, *d_rt_ptr = nullptr, *d_rt_rows = nullptr;
+    uint32_t n_tiles = 0, n_row_tiles = 0;
+    int64_t tile_nnz = 0;
+    int64_t tile_hist[3] = {0, 0, 0}, tile_cells = 0;  // detector report
+    bool tile_hist_valid = false;
+    uint32_t panel_rows = 0;
+    uint32_t n_tasks = 0, n_chunks = 0, n_slots = 0, n_split = 0, n_partials = 0;  // n_slots: chunk table incl. padding
+    uint64_t n_records = 0;   // nnz + padding
+    int64_t c_rows = 0;       // rows of C the plan writes into (m, or hostA->m for a mapped plan)
+    int64_t device_bytes = 0;
+    double plan_ms = 0;
+    bool has_stats = false;
+    flex_plan_stats stats{};
+};
+
+namespace flex {
+
+// A positive integer from the environment, or `dflt` (plan-time tuning knobs; nothing in the product sets them).
+long env_long(const char *name, long dflt);
+
+template <typename T>
+int upload(T **dptr, const std::vector<T> &h, int64_t *bytes) {
+    *dptr = nullptr;
+    const size_t nb = (h.empty() ? 1 : h.size()) * sizeof(T);
+    FLEX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(dptr), nb));
+    if (!h.empty()) FLEX_HIP_TRY(hipMemcpy(*dptr, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *bytes += static_cast<int64_t>(nb);
+    return FLEX_OK;
+}
+
+void free_plan_device(flex_plan *p);
+
+// The kernels' view of a finished plan.  `fused`: split rows are summed inside the launch.
+inline PlanView plan_view(const flex_plan *p, bool fused, uint64_t *trace) {
+    return PlanView{p->d_rec, p->d_t_beg, p->d_t_dst, p->d_t_aux, p->d_chunk, p->d_partial, p->d_split, p->d_split_cnt,
+                    fused ? 1u : 0u, p->n_slots, p->k, p->ldb, p->ldc,
+                    p->xcd_remap ? 1u : 0u, p->lds_extra, p->rec_nt ? 1u : 0u, trace};
+}
+inline TileView tile_view(const flex_plan *p) { return TileView{p->d_tile_a, p->d_tile_boff, p->d_rt_ptr, p->d_rt_rows, p->n_row_tiles}; }
+// float4 path: k and both strides multiples of 4, both base addresses 16-byte aligned
+inline bool operands_vec4(const flex_plan *p, const float *dB, const float *dC) {
+    return (p->k % 4 == 0) && (p->ldb % 4 == 0) && (p->ldc % 4 == 0) &&
+           ((reinterpret_cast<uintptr_t>(dB) | reinterpret_cast<uintptr_t>(dC)) % 16 == 0);
+}
+
+// Rows [r0,r1) of A.  col_map: B row read by column c (NULL = c).  dst_map: C row written by row r (NULL = r - r0,
+// i.e. slice-local).  sched_cache (or NULL): holds the row schedule once it has been computed, so that several
+// candidate plans of one matrix (autotune) order it only once.  force_G (or 0): lanes per record instead of the degree rule.
+int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const int32_t *col_map, const int32_t *dst_map,
+               unsigned flags, std::vector<uint32_t> *sched_cache = nullptr, int force_G = 0);
+
+// ---- block-density detector (dense_tiles.cpp)
+struct DenseTiles {
+    std::vector<float> a;           // [T][4][64][4]
+    std::vector<uint32_t> boff;     // [T][32]
+    std::vector<uint32_t> rt_ptr;   // [R+1]
+    std::vector<uint32_t> rt_rows;  // [R][32]
+    int64_t nnz = 0;                // entries moved into tiles
+    int64_t hist_nnz[3] = {0, 0, 0};
+    int64_t n_cells = 0;            // (row tile, column tile) pairs with at least one entry
+};
+// stride > 1: look at every stride-th row tile only (thr must be 0)
+int detect_dense_tiles(const flex_csr *A, int32_t r0, int32_t m, const std::vector<uint32_t> &sched, const std::vector<uint32_t> &colpos,
+                       const int32_t *col_map, const int32_t *dst_map, bool off32, uint32_t row_bytes32, uint32_t thr, int64_t stride,
+                       std::vector<uint8_t> &in_tile, DenseTiles &out);
+
+// ---- plan_check.cpp
+void collect_stats(flex_plan *p, const std::vector<uint2> &rec, const std::vector<uint4> &chunk, int64_t split_nnz);
+
+}  // namespace flex

@@ -1,0 +1,640 @@
+// plan_build.cpp -- the planner: rows [r0,r1) of a host CSR -> the device image the kernels read.
+//
+// PlanBuilder::run() is the list of stages; each stage is one member function that reads what the stages before it
+// left in the builder and leaves its own result there:
+//
+//   choose_tile_width      G lanes per record (column tile of 4G columns), 32- or 64-bit B addressing
+//   order_rows             sched[i] = row processed i-th (natural / RCM / community / Gorder), colpos = its inverse
+//   route_dense_tiles      detector report; 32x32 tiles dense enough for the MFMA kernel leave the record stream
+//   read_knobs             chunk budget, piece length, 2-D panel size ... (rules measured on MI355X, env overrides)
+//   cut_rows_into_pieces   a row is one piece, or several: by length (hubs) and, in 2-D, by column panel
+//   slice_rows_for_xcds    2-D: the eight row slices (1-D cuts the chunk table by cost instead, below)
+//   order_pieces           emission order: schedule order, or per slice phase by phase
+//   number_split_rows      rows summed from several pieces: consecutive partial slots + the arrival bookkeeping
+//   pack_tasks_into_chunks one task per piece, tasks packed into per-wave chunks of about one budget
+//   fill_records           {B-row offset, value} per nonzero, padded to whole steps (parallel over tasks)
+//   upload_tasks           records / tasks / dense tiles to the device
+//   build_chunk_table      chunk headers in launch order, cut into eight cost-balanced XCD slices; statistics; the
+//                          split-row workspace
+//
+// The result does not depend on the number of host threads (tests/test_planner_host.py compares the images).
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <numeric>
+
+#include "host_parallel.h"
+#include "plan.h"
+
+namespace flex {
+
+namespace {
+
+// A run of one row's records that one task processes.
+struct Piece {
+    uint32_t spos;       // position of the piece's row in the schedule
+    uint32_t beg, end;   // its records [beg,end) in rcol/rval
+    uint32_t phase;      // 0 in 1-D; column panel + 1, or kFarPhase, in 2-D
+    uint32_t own_chunk;  // a slice of a run longer than one budget: a chunk of its own
+};
+constexpr uint32_t kFarPhase = 0xFFFFFFFEu;
+constexpr uint32_t kMaxTasksPerWave = 63;  // the kernel hands descriptors out by lane (compute_chunk)
+
+class PlanBuilder {
+   public:
+    PlanBuilder(flex_plan *plan, const flex_csr *csr, int32_t row_begin, int32_t row_end, const int32_t *col_map_, const int32_t *dst_map_,
+                unsigned flags_, std::vector<uint32_t> *sched_cache_, int force_G_)
+        : p(plan), A(csr), r0(row_begin), r1(row_end), m(row_end - row_begin), k(plan->k), col_map(col_map_), dst_map(dst_map_),
+          flags(flags_), order(flags_ & FLEX_ORDER_MASK), force_G(force_G_), sched(sched_cache_ ? *sched_cache_ : sched_local),
+          have_cache(sched_cache_ != nullptr), timing(std::getenv("FLEX_PLAN_TIMING") != nullptr), t_last(std::chrono::steady_clock::now()) {}
+
+    int run() {
+        if (order > FLEX_ORDER_GORDER) return FLEX_ERR_INVALID;
+        // graph orderings need the whole square matrix
+        if (order != FLEX_ORDER_NATURAL && (A->m != A->n || r0 != 0 || r1 != A->m)) return FLEX_ERR_INVALID;
+        p->order = order;
+        int rc;
+        choose_tile_width();
+        if ((rc = order_rows())) return rc;
+        lap("row schedule");
+        if ((rc = route_dense_tiles())) return rc;
+        lap("dense-tile detector");
+        read_knobs();
+        if ((rc = cut_rows_into_pieces())) return rc;
+        lap("pieces");
+        slice_rows_for_xcds();
+        order_pieces();
+        lap("emission order");
+        number_split_rows();
+        if ((rc = pack_tasks_into_chunks())) return rc;
+        fill_records();
+        lap("records and tasks");
+        if ((rc = upload_tasks())) return rc;
+        lap("upload records/tasks");
+        if ((rc = build_chunk_table())) return rc;
+        lap("chunk table, stats");
+        return FLEX_OK;
+    }
+
+   private:
+    // ---- inputs
+    flex_plan *const p;
+    const flex_csr *A;  // after route_dense_tiles: A minus the entries that moved into tiles
+    const int32_t r0, r1, m;
+    const int k;
+    const int32_t *const col_map;  // B row read by column c (NULL = c)
+    const int32_t *const dst_map;  // C row written by row r (NULL = r - r0)
+    const unsigned flags, order;
+    const int force_G;
+    std::vector<uint32_t> sched_local;
+    std::vector<uint32_t> &sched;  // sched[i] = row of A processed i-th
+    const bool have_cache;
+    const bool timing;  // FLEX_PLAN_TIMING: phase times on stderr
+    std::chrono::steady_clock::time_point t_last;
+
+    // ---- stage results
+    int G = 8;                     // lanes per record
+    uint32_t S = 8;                // records per step = 64 / G: tasks are padded to it
+    double avg_deg = 0.0;          // of the rows as given (before tiles leave)
+    std::vector<uint32_t> colpos;  // position of a column's vertex in the schedule; empty = the column id itself
+    DenseTiles tiles;
+    flex_csr A_f{};                // the filtered copy of A (same rows, same ids)
+    std::vector<uint32_t> f_rowptr, f_col;
+    std::vector<float> f_vals;
+    // knobs
+    uint32_t wave_nnz = 0, row_cost = 16, long_row = 0, piece_len = 0, seg_min = 4, pshift = 0;
+    bool two_d = false;
+    // pieces
+    std::vector<Piece> pieces;
+    std::vector<uint32_t> row_first_piece;  // [m+1] pieces of schedule position i
+    std::vector<uint32_t> pcol;             // 2-D: the records of every row re-grouped by piece (index e - e_base)
+    std::vector<float> pval;
+    const uint32_t *rcol = nullptr;  // where piece ranges point: A's arrays (1-D) or pcol/pval (2-D)
+    const float *rval = nullptr;
+    uint32_t slice_row[kXcds + 1] = {0};  // 2-D: schedule positions of the XCD slices
+    std::vector<uint32_t> emit;           // piece index of task t
+    // split rows
+    std::vector<SplitRow> split;
+    std::vector<uint32_t> row_sidx, row_first_partial;
+    uint32_t n_partials = 0;
+    int64_t split_nnz = 0;
+    // tasks, chunks, records
+    std::vector<uint32_t> t_beg, t_dst, w_task;  // w_task[c] = first task of chunk c (+ sentinel)
+    std::vector<uint2> t_aux, rec;
+    uint32_t slice_chunk[kXcds + 1] = {0};  // 2-D: first chunk of each XCD slice
+
+    void lap(const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "plan: %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    }
+    uint32_t dst_of(uint32_t r) const { return dst_map ? static_cast<uint32_t>(dst_map[r]) : r - static_cast<uint32_t>(r0); }
+    int64_t slice_nnz() const { return static_cast<int64_t>(A->rowPtr[r1]) - A->rowPtr[r0]; }
+
+    // G lanes x float4 cover one column tile of 4*G columns; k wider than that runs as several tiles
+    // (blockIdx.y, dispatched one after the other).  Widest tile (fewest instructions per byte) for
+    // low-degree graphs; high-degree graphs are bound by L2-miss traffic instead -- the B rows touched by
+    // the resident waves (waves x records x 16*G bytes) overflow the 4 MiB L2s -- and a narrower tile
+    // shrinks that footprint at the price of re-reading the records once per tile.  Measured on MI355X,
+    // k=128: reddit-like generator, G=16 vs 32: -7 % at degree 12, +7 % at 24, +15 % at
+    // 36..100; amazon shape +12 % (G=16), +16 % (G=8); flickr (degree 11) -7 %, yelp (19.5) -2.5 %.
+    void choose_tile_width() {
+        avg_deg = m > 0 ? static_cast<double>(A->rowPtr[r1] - A->rowPtr[r0]) / m : 0.0;
+        G = 8;
+        while (4 * G < k && G < 64) G <<= 1;
+        if (force_G) {
+            G = std::min(G, force_G);
+        } else if (const long g_env = env_long("FLEX_LANES", 0); g_env == 8 || g_env == 16 || g_env == 32 || g_env == 64) {
+            G = std::min<int>(G, static_cast<int>(g_env));  // tuning experiments
+        } else {
+            G = std::min(G, 32);  // k = 256 as two 128-column tiles beats one 256-column tile on every shape measured
+            if (avg_deg >= 24.0) G = std::min(G, 16);
+            if (avg_deg >= 128.0) G = std::min(G, 8);
+        }
+        S = 64u / static_cast<uint32_t>(G);
+        p->lanes_per_nz = G;
+        p->off32 = static_cast<uint64_t>(A->n) * static_cast<uint64_t>(p->ldb) * 4u <= (uint64_t(1) << 32);
+    }
+
+    int order_rows() {
+        if (have_cache && sched.size() == static_cast<size_t>(m) && m > 0) {
+            // computed by an earlier candidate of the same matrix
+        } else if (sched.assign(static_cast<size_t>(m), 0u); order != FLEX_ORDER_NATURAL) {
+            std::vector<uint32_t> rank;
+            const int rc = order == FLEX_ORDER_RCM       ? order_rcm_host(m, A->rowPtr, A->col, rank)
+                           : order == FLEX_ORDER_CLUSTER ? order_cluster_host(m, A->rowPtr, A->col, rank)
+                                                         : order_gorder_host(m, A->rowPtr, A->col, 3, rank);
+            if (rc) {
+                sched.clear();
+                return rc;
+            }
+            for (int32_t r = 0; r < m; ++r) sched[rank[r]] = static_cast<uint32_t>(r);
+        } else {
+            std::iota(sched.begin(), sched.end(), static_cast<uint32_t>(r0));
+        }
+        // position of a column's vertex in the schedule (what "near" means for a reordered square matrix); for a
+        // natural-order plan, a mapped plan or a row shard the column ids of A are positions already
+        if (order != FLEX_ORDER_NATURAL) {
+            colpos.resize(static_cast<size_t>(m));
+            for (int32_t i = 0; i < m; ++i) colpos[sched[i]] = static_cast<uint32_t>(i);
+        }
+        return FLEX_OK;
+    }
+
+    // Dense tiles -> MFMA kernel (FLEX_MFMA: 1 = route tiles of fill >= FLEX_MFMA_FILL %, 2 = never; default:
+    // route when a sampled look at every 64th row tile finds at least 10 % of the nonzeros in such tiles -- most
+    // graphs have none and then pay 1/64 of one pass).  With FLEX_PLAN_STATS the detector looks at every tile, so
+    // that its report (share of nonzeros in tiles of fill >= 0.10 / 0.25 / 0.50) is exact.
+    // Default threshold 60 %: measured on MI355X at k = 128 (tools/probe_mfma.py, 64-row diagonal blocks + 8 random
+    // entries per row, 200 K rows): routing blocks of fill 0.9 takes 297 -> 220 us, fill 0.6 228 -> 219 (break-even),
+    // fill 0.3 160 -> 217 (slower: a tile costs the same whatever its fill, and its 32 C rows are read and written
+    // once more), DESIGN.md 3.5.
+    int route_dense_tiles() {
+        const long mode_mfma = env_long("FLEX_MFMA", 0);
+        const uint32_t fill_pct = static_cast<uint32_t>(std::clamp<long>(env_long("FLEX_MFMA_FILL", 60), 1, 100));
+        const uint32_t thr = (1024u * fill_pct + 99u) / 100u;
+        const bool report = (flags & FLEX_PLAN_STATS) != 0;
+        const int64_t nnz_in = slice_nnz();
+        const uint32_t row_bytes32 = static_cast<uint32_t>(p->ldb) * 4u;
+        bool route = mode_mfma == 1;
+        std::vector<uint8_t> in_tile;
+        int rc = FLEX_OK;
+        if (mode_mfma != 1 && mode_mfma != 2 && m >= 2048 && nnz_in >= (1 << 16)) {  // the sampled look
+            DenseTiles probe;
+            if ((rc = detect_dense_tiles(A, r0, m, sched, colpos, col_map, dst_map, p->off32, row_bytes32, 0, 64, in_tile, probe))) return rc;
+            const int64_t share = fill_pct <= 10 ? probe.hist_nnz[0] : fill_pct <= 25 ? probe.hist_nnz[1] : probe.hist_nnz[2];  // >= 0.5 also screens for 0.6
+            route = share * 64 * 10 >= nnz_in;  // >= 10 % of the nonzeros, extrapolated from the sample (amazon shape: 2.3 % in
+                                                //    such tiles; routing them changed nothing, 9.08 vs 9.08 ms, and cost 1.1 s of planning)
+        }
+        if (route || report) {
+            if (route) in_tile.assign(static_cast<size_t>(nnz_in), 0);
+            if ((rc = detect_dense_tiles(A, r0, m, sched, colpos, col_map, dst_map, p->off32, row_bytes32, route ? thr : 0, 1, in_tile, tiles))) return rc;
+            p->tile_hist[0] = tiles.hist_nnz[0];
+            p->tile_hist[1] = tiles.hist_nnz[1];
+            p->tile_hist[2] = tiles.hist_nnz[2];
+            p->tile_cells = tiles.n_cells;
+            p->tile_hist_valid = true;
+        }
+        if (tiles.nnz == 0) return FLEX_OK;
+        // the vector kernel gets A minus the entries that moved into tiles (same rows, same ids)
+        f_rowptr.assign(static_cast<size_t>(A->m) + 1, 0u);
+        f_col.resize(static_cast<size_t>(nnz_in - tiles.nnz));
+        f_vals.resize(static_cast<size_t>(nnz_in - tiles.nnz));
+        const uint32_t eb = A->rowPtr[r0];
+        uint32_t o = 0;
+        for (int32_t r = 0; r < A->m; ++r) {
+            f_rowptr[r] = o;
+            if (r < r0 || r >= r1) continue;
+            for (uint32_t e = A->rowPtr[r]; e < A->rowPtr[r + 1]; ++e)
+                if (!in_tile[e - eb]) {
+                    f_col[o] = A->col[e];
+                    f_vals[o] = A->vals[e];
+                    ++o;
+                }
+        }
+        f_rowptr[A->m] = o;
+        A_f = flex_csr{A->m, A->n, static_cast<int64_t>(o), f_rowptr.data(), f_col.data(), f_vals.data()};
+        A = &A_f;
+        return FLEX_OK;
+    }
+
+    void read_knobs() {
+        // chunk budget in records: short chunks keep the dispatcher's load balancing fine-grained on low-degree
+        // graphs (flickr: best at ~96 records), long ones amortise the per-chunk descriptor chain on
+        // high-degree graphs (reddit: best at >= 256).  Measured on MI355X, DESIGN.md 3.3.
+        // (k <= 32, G = 8: a step consumes 8 records, so the same number of steps needs more records per chunk --
+        //  flickr k=32 best at 192, ppi 192, yelp 256, pubmed 128; 7-23 % over the k=128 rule)
+        // (round 2, G = 8 again: the upper clamp was 256; amazon shape k=128 9.08 -> 8.87 ms and k=32 2.34 -> 2.26 ms at 512,
+        //  reddit k=32 174 -> 165 us at 512, yelp k=32 131 -> 126 us at 384 (its rule value: 16 x 19.5 = 312); 768-1024 lose
+        //  it again; G = 16 (reddit k=128) is flat from 256 to 512 and keeps 256)
+        const long lo_budget = G <= 8 ? 128 : 96;
+        long auto_budget = std::clamp<long>(static_cast<long>((G <= 8 ? 16.0 : 8.0) * avg_deg), lo_budget, G <= 8 ? 512 : 256);
+        // small inputs: keep at least ~2048 chunks (two waves per SIMD) before growing them (wiki-Vote shape, k=32:
+        // 5.5 us at 128-160 records per chunk, 6.3 at 200)
+        auto_budget = std::min(auto_budget, std::max<long>(lo_budget, static_cast<long>(A->rowPtr[r1] - A->rowPtr[r0]) / 2048));
+        wave_nnz = static_cast<uint32_t>(env_long("FLEX_WAVE_NNZ", auto_budget));
+        row_cost = static_cast<uint32_t>(env_long("FLEX_ROW_COST", 16));
+        p->xcd_remap = env_long("FLEX_XCD_REMAP", 1) != 2;  // 2 = off (tuning experiments only)
+        p->lds_extra = static_cast<unsigned>(env_long("FLEX_LDS_EXTRA", 1)) & ~15u;  // default 0 (1 -> 0)
+        // The record stream is read once per column tile.  Non-temporal loads keep it from displacing B rows in the L2s and
+        // the Infinity Cache, but they also come back slower and sit on the header -> records -> gathers chain of every chunk.
+        // Measured on MI355X (same box each):
+        //   several tiles (k > 4G), stream >= 32 MB:  amazon shape k=128 9.48 -> 9.00 ms, reddit 687 -> 679 us, yelp 524 -> 515 us
+        //   one tile, stream of 0.1-0.2 GB:           reddit k=32 178 -> 196 us, yelp k=32 130 -> 148 us   (worse)
+        //   one tile, stream of 2.1 GB (8x the Infinity Cache): amazon k=32 2.43 -> 2.29 ms
+        //   small streams:                            flickr k=128 37.9 -> 40.4 us                          (worse)
+        // hence: on for multi-tile launches from 32 MB, for single-tile launches only from 1 GiB.  FLEX_REC_NT = 1 / 2 forces.
+        const long nt_env = env_long("FLEX_REC_NT", 0);
+        const int ktiles = (k + 4 * G - 1) / (4 * G);
+        const uint64_t stream_bytes = static_cast<uint64_t>(A->rowPtr[r1] - A->rowPtr[r0]) * 8u;
+        p->rec_nt = nt_env == 1 || (nt_env != 2 && stream_bytes >= (ktiles >= 2 ? (32ull << 20) : (1ull << 30)));
+        p->unroll = static_cast<int>(env_long("FLEX_U", 0));
+        // Rows longer than one budget are cut into pieces of one budget, each a chunk of its own that
+        // writes a k-wide partial sum: one wave keeps only U gathers in flight, so a long row is much
+        // faster as several concurrent pieces (flickr, MI355X: 88 us with no splitting, 43 us with
+        // rows > 192 records split, 40 us with rows > 96 split; reddit is flat from 256 to 512;
+        // DESIGN.md 3.3).  Pieces stay in schedule order: moving them to the
+        // front of the XCD slices helped flickr by 3 % and cost reddit 12 % (half its chunks are pieces).
+        long_row = static_cast<uint32_t>(env_long("FLEX_LONG_ROW", wave_nnz));
+        piece_len = std::max<uint32_t>(S, static_cast<uint32_t>(env_long("FLEX_PIECE", wave_nnz)) / S * S);
+
+        // Column panels (the 2-D schedule; ≙ the column spans of csr2_DiagTiling's rounds 2-3, mat.cu:680-942, and
+        // csr2seg_Cmajor, mat.cu:1192-1269, re-thought for eight private 4 MiB L2s).  An XCD walks ONE contiguous slice of
+        // the rows; in 1-D that slice is walked row by row and the B rows it needs within +-w communities (megabytes)
+        // are evicted between uses.  In 2-D the slice is walked PHASE by PHASE: phase q holds, for every row of the
+        // slice, the records whose column lies in panel q of B (P rows = `panel_bytes` of one column tile, about half an
+        // L2), so whatever the resident waves gather at one time comes from one or two panels and hits the L2 by
+        // construction; the price is that a row with records in several phases is summed from several pieces (a k-wide
+        // partial sum written and read once per piece).  Only runs of >= `seg_min` records of a row in one panel become a
+        // piece; the rest of the row (its scattered columns, which miss either way) is ONE more piece in a last phase.
+        // The rule is "off": decided by measurement; FLEX_2D = 1 forces it on (tests, tuning), any size.
+        two_d = env_long("FLEX_2D", 0) == 1 && m > 0;
+        const uint64_t tile_bytes = 16ull * static_cast<uint64_t>(G);  // one B row of one column tile
+        const uint64_t panel_bytes = static_cast<uint64_t>(env_long("FLEX_PANEL_KB", 2048)) << 10;
+        pshift = 0;
+        while ((2ull << pshift) * tile_bytes <= panel_bytes) ++pshift;  // P = 2^pshift rows of B per panel
+        seg_min = static_cast<uint32_t>(env_long("FLEX_SEG_MIN", 4));
+    }
+
+    // A run of `len` records as pieces: one, or (longer than a budget) several of about one budget.  The last piece to
+    // arrive sums all of them with ONE wave, so a hub of 10^6 nonzeros cut into 10^4 budget-sized pieces spent 0.9 ms
+    // in that sum alone (tools/probe_hub.py: 1263 us against 358 us without the hub): at most 256 pieces per run,
+    // longer ones instead: 564 us (774 pieces: 601 us).
+    void cut_run(std::vector<Piece> &out, uint32_t spos, uint32_t b, uint32_t e, uint32_t phase) const {
+        const uint32_t len = e - b;
+        if (len <= long_row) {
+            out.push_back({spos, b, e, phase, 0u});
+            return;
+        }
+        constexpr uint32_t kMaxPieces = 256;
+        const uint32_t nchunk = std::min<uint32_t>((len + piece_len - 1) / piece_len, kMaxPieces);
+        const uint32_t per = ((len + nchunk - 1) / nchunk + S - 1) / S * S;  // whole steps
+        for (uint32_t c0 = b; c0 < e; c0 += per) out.push_back({spos, c0, std::min(e, c0 + per), phase, 1u});
+    }
+
+    int cut_rows_into_pieces() {
+        row_first_piece.assign(static_cast<size_t>(m) + 1, 0u);
+        rcol = A->col;
+        rval = A->vals;
+        if (two_d) return cut_by_column_panel();
+        pieces.reserve(static_cast<size_t>(m) + 1024);
+        for (int32_t i = 0; i < m; ++i) {
+            const uint32_t r = sched[i];
+            row_first_piece[i] = static_cast<uint32_t>(pieces.size());
+            cut_run(pieces, static_cast<uint32_t>(i), A->rowPtr[r], A->rowPtr[r + 1], 0u);
+        }
+        row_first_piece[m] = static_cast<uint32_t>(pieces.size());
+        return FLEX_OK;
+    }
+
+    // 2-D: the records of every row are re-grouped by column panel into pcol/pval (index e - e_base); piece ranges
+    // point into those.  Parallel over blocks of schedule positions, block results concatenated in order.
+    int cut_by_column_panel() {
+        const uint32_t e_base = A->rowPtr[r0];
+        pcol.resize(static_cast<size_t>(slice_nnz()));
+        pval.resize(static_cast<size_t>(slice_nnz()));
+        constexpr int64_t kBlk = 1024;  // schedule positions per work item
+        const int64_t nblk = (m + kBlk - 1) / kBlk;
+        std::vector<std::vector<Piece>> blk(static_cast<size_t>(nblk));
+        std::vector<uint32_t> row_np(static_cast<size_t>(m), 0u);
+        std::atomic<int> failed{0};
+        parallel_chunks(nblk, [&](int64_t b) {
+            try {
+                std::vector<Piece> &out = blk[static_cast<size_t>(b)];
+                std::vector<uint64_t> key;  // (panel << 32) | index within the row
+                std::vector<uint32_t> run_beg, run_pan;
+                for (int64_t i = b * kBlk; i < std::min<int64_t>(m, (b + 1) * kBlk); ++i) {
+                    const uint32_t r = sched[i];
+                    const uint32_t e0 = A->rowPtr[r], e1 = A->rowPtr[r + 1], len = e1 - e0;
+                    const size_t before = out.size();
+                    const uint32_t o0 = e0 - e_base;
+                    if (len == 0) {
+                        out.push_back({static_cast<uint32_t>(i), o0, o0, kFarPhase, 0u});
+                        row_np[i] = 1;
+                        continue;
+                    }
+                    key.resize(len);
+                    bool sorted = true;
+                    for (uint32_t z = 0; z < len; ++z) {
+                        const uint32_t c = A->col[e0 + z];
+                        const uint32_t pan = (colpos.empty() ? c : colpos[c]) >> pshift;
+                        key[z] = (static_cast<uint64_t>(pan) << 32) | z;
+                        sorted = sorted && (z == 0 || key[z - 1] <= key[z]);
+                    }
+                    if (!sorted) std::sort(key.begin(), key.end());  // by panel, original order within a panel
+                    run_beg.clear();
+                    run_pan.clear();
+                    for (uint32_t z = 0; z < len; ++z)
+                        if (z == 0 || (key[z] >> 32) != (key[z - 1] >> 32)) {
+                            run_beg.push_back(z);
+                            run_pan.push_back(static_cast<uint32_t>(key[z] >> 32));
+                        }
+                    run_beg.push_back(len);
+                    // layout of the row in pcol/pval: the kept runs in panel order, then everything else
+                    uint32_t o = o0, n_far = 0, n_kept = 0;
+                    auto copy_run = [&](size_t q) {
+                        for (uint32_t z = run_beg[q]; z < run_beg[q + 1]; ++z) {
+                            const uint32_t e = e0 + static_cast<uint32_t>(key[z] & 0xFFFFFFFFu);
+                            pcol[o] = A->col[e];
+                            pval[o] = A->vals[e];
+                            ++o;
+                        }
+                    };
+                    for (size_t q = 0; q + 1 < run_beg.size(); ++q) {
+                        const uint32_t cnt = run_beg[q + 1] - run_beg[q];
+                        if (cnt < seg_min) {
+                            n_far += cnt;
+                            continue;
+                        }
+                        copy_run(q);
+                        ++n_kept;
+                        cut_run(out, static_cast<uint32_t>(i), o - cnt, o, run_pan[q] + 1);
+                    }
+                    const uint32_t far_beg = o;
+                    if (n_far) {
+                        for (size_t q = 0; q + 1 < run_beg.size(); ++q)
+                            if (run_beg[q + 1] - run_beg[q] < seg_min) copy_run(q);
+                        // a remainder too short to pay for a piece of its own rides with the row's last kept run
+                        if (n_far < seg_min && n_kept > 0 && out.back().own_chunk == 0) out.back().end = o;
+                        else cut_run(out, static_cast<uint32_t>(i), far_beg, o, kFarPhase);
+                    }
+                    row_np[i] = static_cast<uint32_t>(out.size() - before);
+                }
+            } catch (...) {
+                failed.store(1);
+            }
+        });
+        if (failed.load()) return FLEX_ERR_NOMEM;
+        size_t total = 0;
+        for (int32_t i = 0; i < m; ++i) {
+            row_first_piece[i] = static_cast<uint32_t>(total);
+            total += row_np[i];
+        }
+        row_first_piece[m] = static_cast<uint32_t>(total);
+        if (total >= (size_t(1) << 31)) return FLEX_ERR_UNSUPPORTED;
+        pieces.resize(total);
+        parallel_chunks(nblk, [&](int64_t b) {
+            const std::vector<Piece> &src = blk[static_cast<size_t>(b)];
+            if (!src.empty()) std::copy(src.begin(), src.end(), pieces.begin() + row_first_piece[b * kBlk]);
+        });
+        rcol = pcol.data();  // piece ranges are relative to e_base
+        rval = pval.data();
+        return FLEX_OK;
+    }
+
+    // 2-D: XCD slices of the rows, cut by records + row overhead (a slice's phases must stay on one XCD).
+    void slice_rows_for_xcds() {
+        std::fill(slice_row, slice_row + kXcds, 0u);
+        slice_row[kXcds] = static_cast<uint32_t>(m);
+        if (!two_d) return;
+        std::vector<uint64_t> cum(static_cast<size_t>(m) + 1, 0);
+        for (int32_t i = 0; i < m; ++i) {
+            const uint32_t r = sched[i];
+            cum[i + 1] = cum[i] + (A->rowPtr[r + 1] - A->rowPtr[r]) + row_cost;
+        }
+        for (int x = 1; x < kXcds; ++x)
+            slice_row[x] = std::max<uint32_t>(slice_row[x - 1], static_cast<uint32_t>(std::lower_bound(cum.begin(), cum.end(), cum[m] * x / kXcds) - cum.begin()));
+    }
+
+    // emission order: 1-D = schedule order; 2-D = per slice, phase by phase (rows in schedule order inside a phase)
+    void order_pieces() {
+        emit.resize(pieces.size());
+        std::iota(emit.begin(), emit.end(), 0u);
+        if (!two_d) return;
+        parallel_chunks(kXcds, [&](int64_t x) {
+            auto b = emit.begin() + row_first_piece[slice_row[x]], e = emit.begin() + row_first_piece[slice_row[x + 1]];
+            std::stable_sort(b, e, [&](uint32_t u, uint32_t v) { return pieces[u].phase < pieces[v].phase; });
+        });
+    }
+
+    // rows summed from several pieces: partial slots (consecutive per row, in piece order) + arrival bookkeeping
+    void number_split_rows() {
+        row_sidx.assign(static_cast<size_t>(m), 0u);
+        row_first_partial.assign(static_cast<size_t>(m), 0u);
+        for (int32_t i = 0; i < m; ++i) {
+            const uint32_t np = row_first_piece[i + 1] - row_first_piece[i];
+            if (np <= 1) continue;
+            const uint32_t r = sched[i];
+            row_sidx[i] = static_cast<uint32_t>(split.size());
+            row_first_partial[i] = n_partials;
+            split.push_back({dst_of(r), n_partials, np});
+            n_partials += np;
+            split_nnz += A->rowPtr[r + 1] - A->rowPtr[r];
+        }
+    }
+
+    // tasks (one per piece, in emission order) and the chunks (one wave each) they are packed into
+    int pack_tasks_into_chunks() {
+        const uint32_t n_tasks = static_cast<uint32_t>(pieces.size());
+        t_beg.resize(static_cast<size_t>(n_tasks) + 1);
+        t_dst.resize(n_tasks);
+        t_aux.resize(n_tasks);
+        uint64_t pos = 0;
+        uint32_t wave_cost = 0, cur_phase = 0, prev_own = 0;
+        int cur_slice = 0;
+        for (uint32_t t = 0; t < n_tasks; ++t) {
+            const Piece &pc = pieces[emit[t]];
+            const uint32_t len = pc.end - pc.beg;
+            bool fresh = w_task.empty() || wave_cost >= wave_nnz || t - w_task.back() >= kMaxTasksPerWave || pc.own_chunk || prev_own;
+            if (two_d) {
+                while (pc.spos >= slice_row[cur_slice + 1]) {  // first task of the next XCD slice
+                    slice_chunk[++cur_slice] = static_cast<uint32_t>(w_task.size());
+                    fresh = true;
+                }
+                if (pc.phase != cur_phase) fresh = true;  // a chunk never straddles two panels
+                cur_phase = pc.phase;
+            }
+            if (fresh) {
+                w_task.push_back(t);
+                wave_cost = 0;
+            }
+            wave_cost += len + row_cost;
+            prev_own = pc.own_chunk;
+            t_beg[t] = static_cast<uint32_t>(pos);
+            pos += (len + S - 1) / S * S;  // padded to a whole number of steps
+            if (pos >= (uint64_t(1) << 32)) return FLEX_ERR_UNSUPPORTED;  // 32-bit record offsets
+        }
+        t_beg[n_tasks] = static_cast<uint32_t>(pos);
+        w_task.push_back(n_tasks);
+        if (m == 0) w_task.assign(1, 0u);
+        if (two_d)
+            while (cur_slice < kXcds) slice_chunk[++cur_slice] = static_cast<uint32_t>(w_task.size() - 1);
+        rec.resize(static_cast<size_t>(pos));
+        return FLEX_OK;
+    }
+
+    void fill_records() {
+        const uint32_t n_tasks = static_cast<uint32_t>(pieces.size());
+        const uint32_t row_bytes32 = static_cast<uint32_t>(p->ldb) * 4u;
+        constexpr int64_t kTaskBlk = 4096;
+        parallel_chunks((static_cast<int64_t>(n_tasks) + kTaskBlk - 1) / kTaskBlk, [&](int64_t b) {
+            for (int64_t t = b * kTaskBlk; t < std::min<int64_t>(n_tasks, (b + 1) * kTaskBlk); ++t) {
+                const uint32_t pi = emit[t];
+                const Piece &pc = pieces[pi];
+                const uint32_t i = pc.spos, r = sched[i];
+                const uint32_t np = row_first_piece[i + 1] - row_first_piece[i];
+                if (np > 1) {
+                    t_dst[t] = kPartialFlag | (row_first_partial[i] + (pi - row_first_piece[i]));
+                    t_aux[t] = make_uint2(row_sidx[i], np);
+                } else {
+                    t_dst[t] = dst_of(r);
+                    t_aux[t] = make_uint2(0u, 0u);
+                }
+                uint2 *o = rec.data() + t_beg[t];
+                for (uint32_t e = pc.beg; e < pc.end; ++e) {
+                    uint32_t c = rcol[e];
+                    if (col_map) c = static_cast<uint32_t>(col_map[c]);
+                    uint32_t bits;
+                    std::memcpy(&bits, &rval[e], 4);
+                    *o++ = make_uint2(p->off32 ? c * row_bytes32 : c, bits);
+                }
+                // pad to a whole number of steps: value 0, B row = the last real one (always a valid address)
+                for (uint2 *end = rec.data() + t_beg[t + 1]; o < end; ++o) *o = make_uint2(o[-1].x, 0u);
+            }
+        });
+        pcol = std::vector<uint32_t>();
+        pval = std::vector<float>();
+    }
+
+    int upload_tasks() {
+        p->n_tasks = static_cast<uint32_t>(pieces.size());
+        p->n_records = rec.size();
+        p->c_rows = dst_map ? A->m : m;
+        p->n_chunks = static_cast<uint32_t>(w_task.size() - 1);
+        p->n_split = static_cast<uint32_t>(split.size());
+        p->n_partials = n_partials;
+        p->two_d = two_d;
+        p->panel_rows = 1u << pshift;
+        int rc;
+        if ((rc = upload(&p->d_rec, rec, &p->device_bytes))) return rc;
+        if ((rc = upload(&p->d_t_beg, t_beg, &p->device_bytes))) return rc;
+        if ((rc = upload(&p->d_t_dst, t_dst, &p->device_bytes))) return rc;
+        if ((rc = upload(&p->d_t_aux, t_aux, &p->device_bytes))) return rc;
+        p->n_tiles = static_cast<uint32_t>(tiles.boff.size() / 32);
+        p->n_row_tiles = tiles.rt_ptr.empty() ? 0u : static_cast<uint32_t>(tiles.rt_ptr.size() - 1);
+        p->tile_nnz = tiles.nnz;
+        if (p->n_tiles) {
+            if ((rc = upload(&p->d_tile_a, tiles.a, &p->device_bytes))) return rc;
+            if ((rc = upload(&p->d_tile_boff, tiles.boff, &p->device_bytes))) return rc;
+            if ((rc = upload(&p->d_rt_ptr, tiles.rt_ptr, &p->device_bytes))) return rc;
+            if ((rc = upload(&p->d_rt_rows, tiles.rt_rows, &p->device_bytes))) return rc;
+        }
+        return FLEX_OK;
+    }
+
+    // Chunk table in launch order: the kernel gives XCD x the x-th eighth of it.  The eighths are cut
+    // by COST (records + per-row and per-chunk overhead), not by chunk count, and padded with empty
+    // chunks to a common length: schedules that put the heavy rows at one end (degree order, RCM,
+    // Gorder) otherwise leave one XCD with up to 1.9x the mean work (flickr shape).
+    // (2-D: the eighths are the row slices cut above -- a slice's phases must stay on one XCD.)
+    int build_chunk_table() {
+        const uint32_t n_real = static_cast<uint32_t>(w_task.size() - 1);
+        auto header = [&](uint32_t c) {
+            return make_uint4(w_task[c], w_task[c + 1] - w_task[c], t_beg[w_task[c]], t_beg[w_task[c + 1]]);
+        };
+        std::vector<uint4> chunk;
+        if (two_d || (p->xcd_remap && n_real >= 8u * kXcds * kWavesPerBlock && env_long("FLEX_XCD_BALANCE", 1) != 2)) {
+            uint32_t cut[kXcds + 1];
+            cut[0] = 0;
+            cut[kXcds] = n_real;
+            if (two_d) {
+                for (uint32_t x = 1; x < kXcds; ++x) cut[x] = slice_chunk[x];
+            } else {
+                // cost of a chunk in units of one 512-byte gather (a record at k = 128): measured per-XCD times
+                // on the flickr shape fit  t = a * records + ~20 a * chunks  with rows nearly free
+                const uint64_t chunk_cost = static_cast<uint64_t>(env_long("FLEX_CHUNK_COST", 16)) * 32u;
+                const uint64_t task_cost = static_cast<uint64_t>(env_long("FLEX_TASK_COST", 2)) * 32u;
+                std::vector<uint64_t> cum(n_real + 1, 0);
+                for (uint32_t c = 0; c < n_real; ++c) {
+                    const uint4 h = header(c);
+                    cum[c + 1] = cum[c] + static_cast<uint64_t>(h.w - h.z) * static_cast<uint32_t>(G) + task_cost * h.y + chunk_cost;
+                }
+                for (uint32_t x = 1; x < kXcds; ++x) {
+                    const uint64_t want = cum[n_real] * x / kXcds;
+                    uint32_t c = static_cast<uint32_t>(std::lower_bound(cum.begin(), cum.end(), want) - cum.begin());
+                    c = (c + kWavesPerBlock / 2) / kWavesPerBlock * kWavesPerBlock;  // whole workgroups
+                    cut[x] = std::clamp(c, cut[x - 1], n_real);
+                }
+            }
+            uint32_t longest = 0;
+            for (uint32_t x = 0; x < kXcds; ++x) longest = std::max(longest, cut[x + 1] - cut[x]);
+            longest = (longest + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock;
+            chunk.assign(static_cast<size_t>(longest) * kXcds, make_uint4(0u, 0u, 0u, 0u));  // empty: no tasks, no records
+            for (uint32_t x = 0; x < kXcds; ++x)
+                for (uint32_t c = cut[x]; c < cut[x + 1]; ++c) chunk[static_cast<size_t>(x) * longest + (c - cut[x])] = header(c);
+        } else {
+            chunk.resize(n_real);
+            for (uint32_t c = 0; c < n_real; ++c) chunk[c] = header(c);
+        }
+        p->n_chunks = n_real;
+        p->n_slots = static_cast<uint32_t>(chunk.size());
+        int rc;
+        if ((rc = upload(&p->d_chunk, chunk, &p->device_bytes))) return rc;
+        if (flags & FLEX_PLAN_STATS) collect_stats(p, rec, chunk, split_nnz);
+        // split-row workspace: the rows, one arrival counter per (row, column tile) -- zero between launches -- and the partial sums
+        if ((rc = upload(&p->d_split, split, &p->device_bytes))) return rc;
+        const size_t ktiles = (static_cast<size_t>(k) + 4 * G - 1) / (4 * G);
+        std::vector<uint32_t> zeros(std::max<size_t>(1, split.size() * ktiles), 0u);
+        if ((rc = upload(&p->d_split_cnt, zeros, &p->device_bytes))) return rc;
+        const size_t pbytes = std::max<size_t>(1, static_cast<size_t>(n_partials) * k) * sizeof(float);
+        p->fused_fixup = env_long("FLEX_FUSED_FIXUP", 1) == 1;
+        FLEX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_partial), pbytes));
+        p->device_bytes += static_cast<int64_t>(pbytes);
+        return FLEX_OK;
+    }
+};
+
+}  // namespace
+
+int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const int32_t *col_map, const int32_t *dst_map, unsigned flags,
+               std::vector<uint32_t> *sched_cache, int force_G) try {
+    return PlanBuilder(p, A, r0, r1, col_map, dst_map, flags, sched_cache, force_G).run();
+} catch (const std::bad_alloc &) {  // any host allocation of any stage
+    return FLEX_ERR_NOMEM;
+}
+
+}  // namespace flex

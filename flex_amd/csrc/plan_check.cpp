@@ -1,0 +1,253 @@
+// plan_check.cpp -- what is read back from a finished plan: the B-reuse / imbalance statistics of the planner's
+// arrays, the self-check of the DEVICE image, and the measured per-CU imbalance (stamped twin of the kernel).
+#include <algorithm>
+#include <new>
+
+#include "plan.h"
+
+using namespace flex;
+
+namespace flex {
+
+// ≙ alpha_stats_collect (mat.cu:944-1065): distinct B rows per chunk / workgroup / XCD slice by
+// stamping, and how evenly records are cut.  Padding records repeat the row's last column, so they
+// change no distinct count.
+void collect_stats(flex_plan *p, const std::vector<uint2> &rec, const std::vector<uint4> &chunk, int64_t split_nnz) {
+    flex_plan_stats &st = p->stats;
+    st = flex_plan_stats{};
+    const uint32_t n_chunks = static_cast<uint32_t>(chunk.size());
+    uint32_t nblk = (n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    nblk = (nblk + kXcds - 1) / kXcds * kXcds;  // as launch_spmm cuts the grid
+    const uint32_t cpx = std::max(1u, nblk / kXcds);
+    const uint32_t row_bytes32 = static_cast<uint32_t>(p->ldb) * 4u;
+    std::vector<uint32_t> seen_wave(p->n, 0u), seen_wg(p->n, 0u), seen_xcd(p->n, 0u);
+    int64_t xcd_rec[kXcds] = {0};
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        const uint32_t wg = c / kWavesPerBlock;
+        const uint32_t xcd = p->xcd_remap ? std::min<uint32_t>(wg / cpx, kXcds - 1) : wg % kXcds;
+        const uint32_t n_rec = chunk[c].w - chunk[c].z;
+        if (chunk[c].y == 0) continue;  // padding slot
+        for (uint32_t z = chunk[c].z; z < chunk[c].w; ++z) {
+            const uint32_t col = p->off32 ? rec[z].x / row_bytes32 : rec[z].x;
+            if (seen_wave[col] != c + 1) seen_wave[col] = c + 1, st.cols_wave++;
+            if (seen_wg[col] != wg + 1) seen_wg[col] = wg + 1, st.cols_wg++;
+            if (seen_xcd[col] != xcd + 1) seen_xcd[col] = xcd + 1, st.cols_xcd++;
+        }
+        xcd_rec[xcd] += n_rec;
+        st.chunk_rec_max = std::max<int64_t>(st.chunk_rec_max, n_rec);
+    }
+    st.records = static_cast<int64_t>(rec.size());
+    st.n_workgroups = nblk;
+    const double nnz = static_cast<double>(p->nnz - p->tile_nnz);  // what the vector kernel processes
+    st.reuse_wave = st.cols_wave ? nnz / st.cols_wave : 0.0;
+    st.reuse_wg = st.cols_wg ? nnz / st.cols_wg : 0.0;
+    st.reuse_xcd = st.cols_xcd ? nnz / st.cols_xcd : 0.0;
+    st.gather_bytes = 4.0 * (p->m + 1) + 8.0 * nnz + 4.0 * nnz * p->k + 4.0 * p->m * p->k;
+    st.l2_bytes = 4.0 * (p->m + 1) + 8.0 * st.records + 4.0 * p->k * st.cols_xcd + 4.0 * p->m * p->k;
+    st.chunk_rec_mean = p->n_chunks ? static_cast<double>(st.records) / p->n_chunks : 0.0;
+    st.chunk_imb_pct = st.chunk_rec_mean > 0 ? 100.0 * st.chunk_rec_max / st.chunk_rec_mean - 100.0 : 0.0;
+    const int64_t xmax = *std::max_element(xcd_rec, xcd_rec + kXcds);
+    st.xcd_imb_pct = st.records ? 100.0 * xmax * kXcds / st.records - 100.0 : 0.0;
+    st.split_nnz_pct = nnz > 0 ? 100.0 * split_nnz / nnz : 0.0;
+    st.pad_pct = nnz > 0 ? 100.0 * (st.records - nnz) / nnz : 0.0;
+    // detector report + what was routed to the MFMA kernel
+    const double all = static_cast<double>(p->nnz);
+    st.tile_nnz_pct_10 = all > 0 ? 100.0 * p->tile_hist[0] / all : 0.0;
+    st.tile_nnz_pct_25 = all > 0 ? 100.0 * p->tile_hist[1] / all : 0.0;
+    st.tile_nnz_pct_50 = all > 0 ? 100.0 * p->tile_hist[2] / all : 0.0;
+    st.tile_mean_fill = p->tile_cells > 0 ? all / (1024.0 * p->tile_cells) : 0.0;
+    st.mfma_tiles = p->n_tiles;
+    st.mfma_nnz_pct = all > 0 ? 100.0 * p->tile_nnz / all : 0.0;
+    p->has_stats = true;
+}
+
+}  // namespace flex
+
+extern "C" {
+
+int flex_plan_measure_imbalance(flex_plan *p, const float *dB, float *dC, flex_stream_t stream, flex_imbalance *out) try {
+    if (!p || !out || !dC || (!dB && p->nnz > 0)) return FLEX_ERR_INVALID;
+    *out = flex_imbalance{};
+    if (p->m == 0 || p->n_slots == 0) return FLEX_OK;
+    if (!operands_vec4(p, dB, dC)) return FLEX_ERR_UNSUPPORTED;  // the stamped twin exists for the vector kernel only
+    int cur = -1;
+    FLEX_HIP_TRY(hipGetDevice(&cur));
+    if (cur != p->device) FLEX_HIP_TRY(hipSetDevice(p->device));
+    const size_t ktiles = (static_cast<size_t>(p->k) + 4 * p->lanes_per_nz - 1) / (4 * p->lanes_per_nz);
+    const size_t words = static_cast<size_t>(p->n_slots) * ktiles * 3;
+    uint64_t *d_log = nullptr;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int rc = FLEX_OK;
+    std::vector<uint64_t> log(words);
+    if (hipMalloc(reinterpret_cast<void **>(&d_log), words * 8) != hipSuccess) rc = FLEX_ERR_HIP;
+    if (!rc && hipMemsetAsync(d_log, 0, words * 8, s) != hipSuccess) rc = FLEX_ERR_HIP;
+    if (!rc) {
+        rc = launch_spmm_stamped(plan_view(p, p->fused_fixup, d_log), p->lanes_per_nz, p->off32, dB, dC, s);
+        if (rc == FLEX_OK && !p->fused_fixup) rc = launch_fixup(p->d_partial, p->d_split, p->n_split, p->k, p->ldc, dC, s);
+        if (rc == FLEX_OK && p->n_tiles) {
+            rc = launch_tiles(tile_view(p), p->off32, dB, dC, p->k, p->ldb, p->ldc, s);
+        }
+    }
+    if (!rc && (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(log.data(), d_log, words * 8, hipMemcpyDeviceToHost) != hipSuccess)) rc = FLEX_ERR_HIP;
+    (void)hipFree(d_log);
+    if (cur != p->device) (void)hipSetDevice(cur);
+    if (rc) return rc;
+    // reduce: CU = (XCC id, SE/SH/CU bits of HW_ID [15:8]); clock = 100 MHz
+    struct Acc {
+        uint64_t busy = 0, first = ~0ull, last = 0;
+    };
+    std::vector<Acc> cu(16 * 256), xcd(16);
+    uint64_t t_min = ~0ull, t_max = 0, busy_all = 0, w_max = 0;
+    int64_t waves = 0;
+    for (size_t i = 0; i < words; i += 3) {
+        const uint64_t t0 = log[i], t1 = log[i + 1], id = log[i + 2];
+        if (t1 == 0 || t1 < t0) continue;  // a padding entry of the chunk table: the wave left before the stamps
+        const uint32_t x = static_cast<uint32_t>(id >> 32) & 15u, c = (static_cast<uint32_t>(id) >> 8) & 255u;
+        for (Acc *a : {&cu[x * 256 + c], &xcd[x]}) {
+            a->busy += t1 - t0;
+            a->first = std::min(a->first, t0);
+            a->last = std::max(a->last, t1);
+        }
+        t_min = std::min(t_min, t0);
+        t_max = std::max(t_max, t1);
+        busy_all += t1 - t0;
+        w_max = std::max(w_max, t1 - t0);
+        ++waves;
+    }
+    if (waves == 0) return FLEX_OK;
+    auto summarise = [&](const std::vector<Acc> &v, int32_t *seen, double *busy_imb, double *end_spread) {
+        uint64_t bmax = 0, bsum = 0, emin = ~0ull, emax = 0;
+        int cnt = 0;
+        for (const Acc &a : v) {
+            if (a.last == 0) continue;
+            ++cnt;
+            bmax = std::max(bmax, a.busy);
+            bsum += a.busy;
+            emin = std::min(emin, a.last);
+            emax = std::max(emax, a.last);
+        }
+        *seen = cnt;
+        *busy_imb = bsum ? 100.0 * bmax * cnt / bsum - 100.0 : 0.0;
+        *end_spread = t_max > t_min ? 100.0 * (emax - emin) / (t_max - t_min) : 0.0;
+    };
+    out->waves = waves;
+    out->span_us = (t_max - t_min) * 0.01;
+    summarise(cu, &out->cus_seen, &out->cu_busy_imb_pct, &out->cu_end_spread_pct);
+    summarise(xcd, &out->xcds_seen, &out->xcd_busy_imb_pct, &out->xcd_end_spread_pct);
+    out->wave_us_mean = busy_all * 0.01 / waves;
+    out->wave_us_max = w_max * 0.01;
+    return FLEX_OK;
+} catch (const std::bad_alloc &) {
+    return FLEX_ERR_NOMEM;
+}
+
+// ≙ the reference's tiler round-trip (mat.cu:905-940: every entry of the pillar format exists exactly once,
+// the queues are contiguous): read the plan's DEVICE image back and check that it is a partition --
+// chunks tile the tasks, tasks tile the records, every record names a valid B row, every C row is written by
+// exactly one task or by exactly one split row whose pieces are contiguous partial slots, padding entries of
+// the chunk table are empty.  Independent of the planner's host arrays: it validates what the kernels read.
+int flex_plan_self_check(const flex_plan *p) try {
+    if (!p) return FLEX_ERR_INVALID;
+    if (p->m == 0) return FLEX_OK;
+    int cur = -1;
+    FLEX_HIP_TRY(hipGetDevice(&cur));
+    if (cur != p->device) FLEX_HIP_TRY(hipSetDevice(p->device));
+    std::vector<uint2> rec(p->n_records), t_aux(p->n_tasks);
+    std::vector<uint32_t> t_beg(static_cast<size_t>(p->n_tasks) + 1), t_dst(p->n_tasks);
+    std::vector<uint4> chunk(p->n_slots);
+    std::vector<SplitRow> split(p->n_split);
+    auto down = [&](void *dst, const void *src, size_t bytes) { return bytes == 0 || hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess; };
+    const bool ok_copy = down(rec.data(), p->d_rec, rec.size() * sizeof(uint2)) && down(t_beg.data(), p->d_t_beg, t_beg.size() * 4) &&
+                         down(t_dst.data(), p->d_t_dst, t_dst.size() * 4) && down(chunk.data(), p->d_chunk, chunk.size() * sizeof(uint4)) &&
+                         down(split.data(), p->d_split, split.size() * sizeof(SplitRow)) && down(t_aux.data(), p->d_t_aux, t_aux.size() * sizeof(uint2));
+    if (cur != p->device) (void)hipSetDevice(cur);
+    if (!ok_copy) return FLEX_ERR_HIP;
+
+    // tasks tile the record stream
+    if (t_beg[0] != 0 || t_beg[p->n_tasks] != p->n_records) return FLEX_ERR_FORMAT;
+    for (uint32_t t = 0; t < p->n_tasks; ++t)
+        if (t_beg[t] > t_beg[t + 1]) return FLEX_ERR_FORMAT;
+    // chunks tile the tasks (in table order, skipping the empty padding entries), each within the kernel's limits
+    uint32_t next_task = 0, real = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> seen;  // real chunks as (first task, #tasks)
+    for (const uint4 &c : chunk) {
+        if (c.y == 0) {
+            if (c.x | c.z | c.w) return FLEX_ERR_FORMAT;
+            continue;
+        }
+        if (c.y > 63 || c.x + c.y > p->n_tasks || c.z != t_beg[c.x] || c.w != t_beg[c.x + c.y]) return FLEX_ERR_FORMAT;
+        seen.emplace_back(c.x, c.y);
+        ++real;
+    }
+    if (real != p->n_chunks) return FLEX_ERR_FORMAT;
+    std::sort(seen.begin(), seen.end());
+    for (const auto &c : seen) {
+        if (c.first != next_task) return FLEX_ERR_FORMAT;
+        next_task += c.second;
+    }
+    if (next_task != p->n_tasks) return FLEX_ERR_FORMAT;
+    // records name valid B rows
+    const uint64_t row_bytes = static_cast<uint64_t>(p->ldb) * 4u;
+    for (const uint2 &r : rec) {
+        const uint64_t col = p->off32 ? r.x / row_bytes : r.x;
+        if (col >= static_cast<uint64_t>(p->n) || (p->off32 && r.x % row_bytes != 0)) return FLEX_ERR_FORMAT;
+    }
+    // every C row exactly once: by one task, or by one split row whose pieces own consecutive partial slots; every
+    // partial slot is written by exactly one task, and that task names its row and the row's piece count (t_aux:
+    // what the arrival counter is compared with).  Pieces of a row need NOT be consecutive tasks (2-D schedules).
+    std::vector<uint8_t> written(static_cast<size_t>(p->c_rows), 0), slot_taken(p->n_partials, 0);
+    for (uint32_t t = 0; t < p->n_tasks; ++t) {
+        const uint32_t d = t_dst[t];
+        if (d & kPartialFlag) {
+            const uint32_t ps = d & ~kPartialFlag;
+            if (ps >= p->n_partials || slot_taken[ps]++) return FLEX_ERR_FORMAT;
+            const uint2 a = t_aux[t];
+            if (a.x >= p->n_split || a.y != split[a.x].count || ps < split[a.x].first || ps >= split[a.x].first + split[a.x].count) return FLEX_ERR_FORMAT;
+        } else {
+            if (d >= p->c_rows || written[d]++) return FLEX_ERR_FORMAT;
+        }
+    }
+    for (uint8_t w : slot_taken)
+        if (w != 1) return FLEX_ERR_FORMAT;
+    uint32_t first = 0;
+    for (uint32_t i = 0; i < p->n_split; ++i) {
+        const SplitRow &sr = split[i];
+        if (sr.first != first || sr.count < 2 || sr.row >= p->c_rows || written[sr.row]++) return FLEX_ERR_FORMAT;
+        first += sr.count;
+    }
+    if (first != p->n_partials) return FLEX_ERR_FORMAT;
+    // dense tiles: the row-tile directory tiles the tile list, every listed C row is valid and named by one row tile only,
+    // every tile column names a valid B row
+    if (p->n_tiles) {
+        std::vector<uint32_t> rt_ptr(static_cast<size_t>(p->n_row_tiles) + 1), rt_rows(static_cast<size_t>(p->n_row_tiles) * 32),
+            boff(static_cast<size_t>(p->n_tiles) * 32);
+        if (cur != p->device) FLEX_HIP_TRY(hipSetDevice(p->device));
+        const bool ok_t = down(rt_ptr.data(), p->d_rt_ptr, rt_ptr.size() * 4) && down(rt_rows.data(), p->d_rt_rows, rt_rows.size() * 4) &&
+                          down(boff.data(), p->d_tile_boff, boff.size() * 4);
+        if (cur != p->device) (void)hipSetDevice(cur);
+        if (!ok_t) return FLEX_ERR_HIP;
+        if (rt_ptr[0] != 0 || rt_ptr[p->n_row_tiles] != p->n_tiles) return FLEX_ERR_FORMAT;
+        for (uint32_t i = 0; i < p->n_row_tiles; ++i)
+            if (rt_ptr[i] >= rt_ptr[i + 1]) return FLEX_ERR_FORMAT;
+        std::vector<uint8_t> in_rt(static_cast<size_t>(p->c_rows), 0);
+        for (uint32_t d : rt_rows) {
+            if (d == 0xFFFFFFFFu) continue;
+            if (d >= p->c_rows || in_rt[d]++) return FLEX_ERR_FORMAT;
+        }
+        for (uint32_t o : boff) {
+            const uint64_t col = p->off32 ? o / row_bytes : o;
+            if (col >= static_cast<uint64_t>(p->n) || (p->off32 && o % row_bytes != 0)) return FLEX_ERR_FORMAT;
+        }
+    }
+    // a full plan (not a row shard of a mapped matrix) writes every row of C
+    if (p->c_rows == p->m)
+        for (uint8_t w : written)
+            if (w != 1) return FLEX_ERR_FORMAT;
+    return FLEX_OK;
+} catch (const std::bad_alloc &) {
+    return FLEX_ERR_NOMEM;
+} catch (...) {
+    return FLEX_ERR_INVALID;
+}
+
+}  // extern "C"

@@ -199,7 +199,7 @@ __device__ __forceinline__ void wait_loads(v4f (&v)[N]) {
 }
 
 // records staged per wave and window: 256 (2 KiB of LDS) on the wide tiles, 512 on the G = 8 tile, whose chunk budget goes up to
-// 512 records (plan.cpp) -- one window per chunk there; measured with the budget
+// 512 records (plan_build.cpp, read_knobs) -- one window per chunk there; measured with the budget
 template <int G>
 constexpr int kWindowRecs = G <= 8 ? 512 : 256;
 
@@ -299,7 +299,7 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
     // Write out the task that ends at the current stream position (and any empty rows behind it).
     // row_end is kept at ~0 once the chunk's tasks are exhausted, so the per-step test in the hot
     // loop is ONE scalar compare.  A task whose destination carries kPartialFlag is a PIECE: one of several
-    // partial sums of a C row (a row longer than one budget, or a row cut by column panel, plan.cpp); it goes to
+    // partial sums of a C row (a row longer than one budget, or a row cut by column panel, plan_build.cpp); it goes to
     // its k-wide slot of `partial`, write-through when the pieces are combined inside this launch.
     auto flush = [&](uint32_t pos) {
         do {
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(OFF32 
     // load per array and are handed out with v_readlane; the header carries the record range, so
     // the record fetch does not wait for them: header -> {descriptors, records} -> gathers.
     const uint4 hdr = p.chunk[chunk];
-    if (hdr.y == 0) return;  // an empty entry that pads this XCD's slice of the table (plan.cpp)
+    if (hdr.y == 0) return;  // an empty entry that pads this XCD's slice of the table (plan_build.cpp, build_chunk_table)
     const uint32_t my_beg = (static_cast<uint32_t>(lane) <= hdr.y) ? p.t_beg[hdr.x + lane] : 0u;
     const uint32_t my_dst = (static_cast<uint32_t>(lane) < hdr.y) ? p.t_dst[hdr.x + lane] : 0u;
     const uint2 my_aux = (static_cast<uint32_t>(lane) < hdr.y) ? p.t_aux[hdr.x + lane] : make_uint2(0u, 0u);  // read at chunk end only
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(float *__restrict__ ds
 template <int G, bool OFF32, int U>
 int launch_v4(const PlanView &v, const float *dB, float *dC, hipStream_t s) {
     // one wave per chunk-table entry, kWavesPerBlock entries per workgroup, a multiple of 8 workgroups so
-    // the XCD slices are equal (plan.cpp pads them).  2 or 8 waves per workgroup measured the same as 4
+    // the XCD slices are equal (build_chunk_table pads them).  2 or 8 waves per workgroup measured the same as 4
     // (the launch is not dispatch-bound: an empty kernel over the same grid takes 3.4 us)
     uint32_t nblk = (v.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
     nblk = (nblk + kXcds - 1) / kXcds * kXcds;

@@ -2,7 +2,7 @@
 //
 // north_star: "MFMA only where RCM/Gorder reordering yields dense block-sparse tiles".  The reference only has a stub
 // there (flex_spmm.cu:1164-1168 prints "tensor core"); the orderings that would feed it are order_gorder.cu:35-143 and
-// DataLoader.cu:789-857.  Here the planner (plan.cpp, detect_dense_tiles) looks at the matrix in SCHEDULE coordinates
+// DataLoader.cu:789-857.  Here the planner (dense_tiles.cpp, detect_dense_tiles) looks at the matrix in SCHEDULE coordinates
 // after the chosen ordering: a 32 x 32 tile (32 consecutive rows of the schedule x 32 consecutive column positions) whose
 // fill reaches the threshold leaves the record stream and is stored as a dense fp32 block; everything else stays with
 // the vector kernel.  This kernel then adds the dense part: one wave per row tile, all dense tiles of that row tile in

@@ -8,12 +8,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _CSRC = os.path.join(_ROOT, "flex_amd", "csrc")
 _OUT = os.path.join(_HERE, "_build", "libflex_hostsim.so")
-HOST_SOURCES = ["plan.cpp", "ingest.cpp", "reorder.cpp", "cluster.cpp", "rabbit.cpp", "gorder.cpp", "shard.cpp", "synth.cpp"]
+HOST_SOURCES = ["plan.cpp", "plan_build.cpp", "plan_check.cpp", "dense_tiles.cpp", "ingest.cpp", "reorder.cpp", "cluster.cpp", "rabbit.cpp", "gorder.cpp", "shard.cpp", "synth.cpp"]
 
 
 def build(extra_flags=(), out=_OUT):
     srcs = [os.path.join(_CSRC, f) for f in HOST_SOURCES] + [os.path.join(_HERE, "shim.cpp")]
-    deps = srcs + [os.path.join(_CSRC, h) for h in ("internal.h", "host_parallel.h")] + [os.path.join(_ROOT, "include", "flex_spmm.h")]
+    deps = srcs + [os.path.join(_CSRC, h) for h in ("internal.h", "plan.h", "host_parallel.h")] + [os.path.join(_ROOT, "include", "flex_spmm.h")]
     if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
         return out
     os.makedirs(os.path.dirname(out), exist_ok=True)

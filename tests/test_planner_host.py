@@ -121,13 +121,25 @@ def test_dense_tile_route_is_consistent(sim, monkeypatch):
 
 
 def test_planner_result_does_not_depend_on_the_thread_count(sim, monkeypatch):
+    """The whole device image -- every byte the planner uploads, fingerprinted by the shim -- for 1, 3 and 8 host threads:
+    1-D with the community ordering, the 2-D schedule, and the dense-tile route."""
+    sim.hostsim_upload_hash.restype = C.c_uint64
+    sim.hostsim_upload_hash.argtypes = [C.c_int]
     a = flex_amd.synth_graph(n=20000, nnz=20000 + 2 * 400000, community=256, p_in=0.6, p_near=0.25, seed=9)
-    monkeypatch.setenv("FLEX_2D", "1")
-    shapes = []
-    for threads in ("1", "3", "8"):
-        monkeypatch.setenv("FLEX_HOST_THREADS", threads)
-        p = flex_amd.Plan(a, 128, order=flex_amd.FLEX_ORDER_CLUSTER | flex_amd.FLEX_PLAN_STATS)
-        p.self_check()
-        i, s = p.info(), p.stats()
-        shapes.append((i["n_tasks"], i["n_chunks"], i["n_slots"], i["n_partials"], i["n_records"], s["cols_wave"], s["cols_xcd"], s["chunk_rec_max"]))
-    assert shapes[0] == shapes[1] == shapes[2]
+    bd = block_dense(4096, 64, 0.8, 6, seed=2)
+    cases = [(a, {}), (a, {"FLEX_2D": "1"}), (bd, {"FLEX_MFMA": "1", "FLEX_MFMA_FILL": "50"}), (bd, {"FLEX_2D": "1", "FLEX_MFMA": "1"})]
+    for g, env in cases:
+        for name in ("FLEX_2D", "FLEX_MFMA", "FLEX_MFMA_FILL"):
+            monkeypatch.delenv(name, raising=False)
+        for name, v in env.items():
+            monkeypatch.setenv(name, v)
+        shapes = []
+        for threads in ("1", "3", "8"):
+            monkeypatch.setenv("FLEX_HOST_THREADS", threads)
+            sim.hostsim_upload_hash(1)
+            p = flex_amd.Plan(g, 128, order=flex_amd.FLEX_ORDER_CLUSTER | flex_amd.FLEX_PLAN_STATS)
+            image = sim.hostsim_upload_hash(1)
+            p.self_check()
+            i, s = p.info(), p.stats()
+            shapes.append((image, i["n_tasks"], i["n_chunks"], i["n_slots"], i["n_partials"], i["n_records"], i["n_tiles"], s["cols_wave"], s["cols_xcd"], s["chunk_rec_max"]))
+        assert shapes[0] == shapes[1] == shapes[2], env
