@@ -358,11 +358,16 @@ TRAFFIC_SOURCES = ("spmm_kernels.hip", "plan.h", "plan.cpp", "plan_build.cpp", "
 
 
 def traffic_source_hash():
-    """Fingerprint of the sources that decide how many bytes a launch moves (kernel, planner, ordering, generator)."""
+    """Fingerprint of the sources that decide how many bytes a launch moves (kernel, planner, ordering, generator):
+    their CODE -- `//` comments, blank lines and indentation do not count, so that rewording a comment does not
+    void a measurement."""
     import hashlib
     h = hashlib.sha256()
     for f in TRAFFIC_SOURCES:
-        h.update(open(os.path.join(ROOT, "flex_amd", "csrc", f), "rb").read())
+        for line in open(os.path.join(ROOT, "flex_amd", "csrc", f), encoding="utf-8"):
+            code = line.split("//", 1)[0].strip()
+            if code:
+                h.update(code.encode() + b"\n")
     return h.hexdigest()[:16]
 
 

@@ -126,7 +126,8 @@ struct Clusterer {
     //                 of its choice unless u has absorbed something this round, or the gain -- re-priced with r's
     //                 degree as it stands now, so that a popular community does not swallow a whole round of
     //                 proposers -- is no longer positive (then u proposes again next round);
-    //  C (parallel over the absorbing communities) adjacency lists of the absorbed are appended to their new root's.
+    //  C (sequential, O(#merges)) what the absorbed communities held is HANDED to their new roots -- vertex ids for rows still in
+    //                 the CSR, whole lists (moved, never copied) otherwise -- and read when the root is next examined.
     // (Round 1 of this project examined and merged one community at a time, each seeing every earlier merge: the
     //  Amazon shape spent 8.4 s of its 9.3 s plan there, single-threaded.)
     void run(int max_rounds) {
