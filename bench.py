@@ -263,6 +263,10 @@ def main():
         out["roofline"]["model_gather_floor_ms"] = round(gather_demand / 18.6e12 * 1e3, 6)
         if out["roofline"]["traffic"] is not None:
             out["roofline"]["model_fabric_ms"] = round(out["roofline"]["traffic"] / 6.3e12 * 1e3, 6)
+            # the north_star's "rocprof-measured HBM GB/s against the chip's peak": PMC bytes of the launch (memory side of
+            # the L2s: HBM + Infinity Cache) over the launch time measured here; `frac` above is the ALGORITHMIC bytes' share
+            out["roofline"]["traffic_GBps"] = round(out["roofline"]["traffic"] / (kern_ms * 1e-3) / 1e9, 1)
+            out["roofline"]["traffic_frac_of_peak"] = round(out["roofline"]["traffic"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if per_rank is not None:
             nnzs = [r[2] for r in per_rank]
             out["config"]["per_rank_ms"] = [round(r[1] / args.steps, 6) for r in per_rank]        # HIP events, per step
