@@ -258,7 +258,14 @@ class PlanBuilder {
         auto_budget = std::min(auto_budget, std::max<long>(lo_budget, static_cast<long>(A->rowPtr[r1] - A->rowPtr[r0]) / 2048));
         wave_nnz = static_cast<uint32_t>(env_long("FLEX_WAVE_NNZ", auto_budget));
         row_cost = static_cast<uint32_t>(env_long("FLEX_ROW_COST", 16));
-        p->xcd_remap = env_long("FLEX_XCD_REMAP", 1) != 2;  // 2 = off (tuning experiments only)
+        // Contiguous XCD slices (workgroup ids remapped) keep a community's rows on ONE private L2; they pay when the
+        // eighths of the schedule run at different speeds, because a slice cannot borrow an idle XCD.  Community and
+        // natural order: remap on (reddit k=128 cluster 676 vs 811 us without, flickr 38 vs 49, yelp 523 vs 688; natural
+        // order the same either way).  RCM / Gorder (BFS-like orders: the eighths differ in L2 hit rate, so cost-balanced
+        // slices end 20-34 % apart): the hardware's round-robin over XCDs is faster -- reddit RCM 1160 -> 1102 us (k=32:
+        // 260 -> 251), yelp RCM 973 -> 911, flickr RCM 63.8 -> 60.9, flickr Gorder 59.1 -> 52.7.  FLEX_XCD_REMAP = 1 / 2 forces.
+        const long remap_env = env_long("FLEX_XCD_REMAP", 0);
+        p->xcd_remap = remap_env == 1 || (remap_env != 2 && order != FLEX_ORDER_RCM && order != FLEX_ORDER_GORDER);
         p->lds_extra = static_cast<unsigned>(env_long("FLEX_LDS_EXTRA", 1)) & ~15u;  // default 0 (1 -> 0)
         // The record stream is read once per column tile.  Non-temporal loads keep it from displacing B rows in the L2s and
         // the Infinity Cache, but they also come back slower and sit on the header -> records -> gathers chain of every chunk.

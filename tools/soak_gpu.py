@@ -31,7 +31,7 @@ KNOBS = {
     "FLEX_FUSED_FIXUP": [None, None, None, "2"],
     "FLEX_REC_NT": [None, "1", "2"],
     "FLEX_U": [None, None, "8"],
-    "FLEX_XCD_REMAP": [None, None, "2"],
+    "FLEX_XCD_REMAP": [None, "1", "2"],
     "FLEX_XCD_BALANCE": [None, None, "2"],
     "FLEX_LDS_EXTRA": [None, None, "16384"],
     "FLEX_HOST_THREADS": [None, "1", "3", "16"],
