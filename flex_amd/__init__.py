@@ -14,6 +14,7 @@ from .binding import (  # noqa: F401
     FLEX_PLAN_STATS,
     FLEX_PLAN_AUTOTUNE,
     FLEX_PLAN_ROW_RANGE,
+    FLEX_PLAN_XCD_INTERLEAVE,
     FlexError,
     HostCsr,
     Plan,

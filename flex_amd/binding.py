@@ -24,6 +24,7 @@ FLEX_ORDER_GORDER = 3
 FLEX_PLAN_STATS = 0x100
 FLEX_PLAN_AUTOTUNE = 0x200
 FLEX_PLAN_ROW_RANGE = 0x1000
+FLEX_PLAN_XCD_INTERLEAVE = 0x2000
 
 
 class FlexError(RuntimeError):

@@ -13,7 +13,10 @@ void Mat::csr2_DiagTiling() {
     // a reordered loader hands its vo_mp so that B stays un-permuted and C comes back in the
     // original row order (the reference needs permuteX + segVoMap for that)
     const int32_t *vo = dl.vertex_order_abbr == "OVO" ? nullptr : dl.vo_mp.data();
-    FLEX_CHECK(flex_plan_create_mapped(&plan, &a, vo, k, device, schedule | FLEX_PLAN_STATS));
+    // a loader in a BFS-like order (RCM / Gorder), planned as given: no contiguous XCD slices (flex_spmm.h)
+    const std::string &ord = dl.vertex_order_abbr;
+    const unsigned deal = (schedule == FLEX_ORDER_NATURAL && (ord == "RCM" || ord == "GOR")) ? FLEX_PLAN_XCD_INTERLEAVE : 0u;
+    FLEX_CHECK(flex_plan_create_mapped(&plan, &a, vo, k, device, schedule | FLEX_PLAN_STATS | deal));
 }
 
 void Mat::launch_prep() {

@@ -152,7 +152,7 @@ static int create_common(flex_plan **out, const flex_csr *hostA, int64_t row_beg
     if (ldc == 0) ldc = k;
     if (ldb < k || ldc < k) return FLEX_ERR_INVALID;
     const unsigned order = flags & FLEX_ORDER_MASK;
-    if (order > FLEX_ORDER_GORDER || (flags & ~(FLEX_ORDER_MASK | FLEX_PLAN_STATS | FLEX_PLAN_AUTOTUNE))) return FLEX_ERR_INVALID;
+    if (order > FLEX_ORDER_GORDER || (flags & ~(FLEX_ORDER_MASK | FLEX_PLAN_STATS | FLEX_PLAN_AUTOTUNE | FLEX_PLAN_XCD_INTERLEAVE))) return FLEX_ERR_INVALID;
     int rc = validate_csr(hostA);
     if (rc) return rc;
     if (hostA->m >= INT32_MAX) return FLEX_ERR_UNSUPPORTED;

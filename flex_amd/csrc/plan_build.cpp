@@ -265,7 +265,9 @@ class PlanBuilder {
         // slices end 20-34 % apart): the hardware's round-robin over XCDs is faster -- reddit RCM 1160 -> 1102 us (k=32:
         // 260 -> 251), yelp RCM 973 -> 911, flickr RCM 63.8 -> 60.9, flickr Gorder 59.1 -> 52.7.  FLEX_XCD_REMAP = 1 / 2 forces.
         const long remap_env = env_long("FLEX_XCD_REMAP", 0);
-        p->xcd_remap = remap_env == 1 || (remap_env != 2 && order != FLEX_ORDER_RCM && order != FLEX_ORDER_GORDER);
+        // A reordered loader planned as given says so itself: FLEX_PLAN_XCD_INTERLEAVE.
+        const bool interleave = order == FLEX_ORDER_RCM || order == FLEX_ORDER_GORDER || (flags & FLEX_PLAN_XCD_INTERLEAVE) != 0;
+        p->xcd_remap = remap_env == 1 || (remap_env != 2 && !interleave);
         p->lds_extra = static_cast<unsigned>(env_long("FLEX_LDS_EXTRA", 1)) & ~15u;  // default 0 (1 -> 0)
         // The record stream is read once per column tile.  Non-temporal loads keep it from displacing B rows in the L2s and
         // the Infinity Cache, but they also come back slower and sit on the header -> records -> gathers chain of every chunk.

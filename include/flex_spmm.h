@@ -68,6 +68,11 @@ typedef struct flex_plan flex_plan;
                                      size, keep the fastest.  Costs two extra plans and, for the duration of the call,
                                      device memory for one B and one C */
 #define FLEX_PLAN_ROW_RANGE 0x1000u /* flex_plan_create_ex only: desc->row_begin/row_end name a row shard */
+#define FLEX_PLAN_XCD_INTERLEAVE 0x2000u /* deal the chunks round-robin over the 8 XCDs instead of giving each XCD one
+                                            contiguous eighth of the schedule.  For rows that arrive in a BFS-like order
+                                            (a loader reordered by RCM / Gorder and planned as given): eighths of
+                                            such an order run at different speeds.  FLEX_ORDER_RCM and FLEX_ORDER_GORDER
+                                            imply it */
 
 /* ≙ Mat::Mat + csr2_DiagTiling + alpha_transfer (mat.cu:7-31, 680-942, 268-293):
  * builds the row-panel plan for `hostA` and uploads it to `device`.  The reference's

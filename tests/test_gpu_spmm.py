@@ -132,6 +132,18 @@ def test_rcm_schedule_and_mapped_plan_agree_with_natural():
     assert oracle.rescheck(gold, unperm, a.rowPtr)[0] == 0
 
 
+def test_interleaved_xcd_dealing_for_a_reordered_loader():
+    """FLEX_PLAN_XCD_INTERLEAVE (what the C++ host mirror passes for an RCM / Gorder loader): same result as the sliced plan."""
+    a = flex_amd.synth_graph(n=30000, nnz=30000 + 2 * 400000, community=256, p_in=0.6, p_near=0.25, seed=12)
+    B = random_B(a.n, 128, 3)
+    vo, ap = flex_amd.perm_csr(a, flex_amd.order_rcm(a))
+    sliced, dealt = Plan(ap, 128, vo_mp=vo), Plan(ap, 128, vo_mp=vo, order=flex_amd.FLEX_PLAN_XCD_INTERLEAVE)
+    assert dealt.info()["n_slots"] == dealt.info()["n_chunks"] < sliced.info()["n_slots"]
+    c1, c2 = run_plan(sliced, B), run_plan(dealt, B)
+    assert np.array_equal(c1.view(np.uint32), c2.view(np.uint32))  # the same chunks, dealt differently
+    assert_matches_oracle(a, B, c2)
+
+
 def test_row_shards_concatenate_to_full():
     a = random_csr(5000, 5000, 20, seed=21, long_rows={7: 3000})
     k = 128

@@ -120,6 +120,30 @@ def test_dense_tile_route_is_consistent(sim, monkeypatch):
     p3.self_check()
 
 
+def test_xcd_slices_are_a_rule_per_ordering_and_a_flag_for_reordered_loaders(sim):
+    """Contiguous XCD slices (8 equal, padded eighths of the chunk table) for the community and natural orders; a flat
+    table, dealt round-robin by the hardware, for RCM / Gorder and for a mapped plan that says FLEX_PLAN_XCD_INTERLEAVE."""
+    a = flex_amd.synth_graph(n=20000, nnz=20000 + 2 * 300000, community=256, p_in=0.6, p_near=0.25, seed=4)
+    def shape(**kw):
+        p = flex_amd.Plan(a if "vo_mp" not in kw else ap, 128, **kw)
+        p.self_check()
+        i = p.info()
+        return i["n_chunks"], i["n_slots"]
+    vo, ap = flex_amd.perm_csr(a, flex_amd.order_rcm(a))
+    for order in (flex_amd.FLEX_ORDER_CLUSTER, flex_amd.FLEX_ORDER_NATURAL):
+        c, s = shape(order=order)
+        assert s % 8 == 0 and s >= c
+    for order in (flex_amd.FLEX_ORDER_RCM, flex_amd.FLEX_ORDER_GORDER):
+        c, s = shape(order=order)
+        assert s == c
+    c, s = shape(vo_mp=vo)
+    assert s % 8 == 0 and s > c  # a reordered loader planned as given: slices, unless it asks otherwise
+    c2, s2 = shape(vo_mp=vo, order=flex_amd.FLEX_PLAN_XCD_INTERLEAVE)
+    assert s2 == c2 == c
+    with pytest.raises(flex_amd.FlexError):
+        flex_amd.Plan(a, 128, order=0x4000)  # unknown flag bits are refused
+
+
 def test_planner_result_does_not_depend_on_the_thread_count(sim, monkeypatch):
     """The whole device image -- every byte the planner uploads, fingerprinted by the shim -- for 1, 3 and 8 host threads:
     1-D with the community ordering, the 2-D schedule, and the dense-tile route."""
