@@ -33,6 +33,7 @@ struct Clusterer {
     const uint32_t *rowPtr, *col;
     std::vector<uint32_t> parent;                                 // union-find over communities
     std::vector<double> cdeg;                                     // community degree (sum of member degrees)
+    std::vector<uint32_t> deg0;                                   // a vertex's own degree, self loop not counted (kept for the second stage)
     using Adj = std::vector<std::pair<uint32_t, float>>;
     std::vector<Adj> adj;                                          // a community's adjacency as of its last compaction
     std::vector<std::vector<Adj>> segs;                           // + the lists of the communities it has absorbed since (moved, not copied)
@@ -42,7 +43,7 @@ struct Clusterer {
     double M = 0;                                                 // total degree (2m)
 
     Clusterer(int64_t n_, const uint32_t *rp, const uint32_t *c)
-        : n(n_), rowPtr(rp), col(c), parent(n_), cdeg(n_, 0.0), adj(n_), segs(n_), raw(n_, 1), rawm(n_), children(n_) {
+        : n(n_), rowPtr(rp), col(c), parent(n_), cdeg(n_, 0.0), deg0(n_), adj(n_), segs(n_), raw(n_, 1), rawm(n_), children(n_) {
         std::iota(parent.begin(), parent.end(), 0u);
         constexpr int64_t kBlk = 1 << 14;
         const int64_t nblk = (n + kBlk - 1) / kBlk;
@@ -53,6 +54,7 @@ struct Clusterer {
                 uint32_t d = 0;
                 for (uint32_t e = rowPtr[u]; e < rowPtr[u + 1]; ++e) d += (col[e] != u);
                 cdeg[u] = d;
+                deg0[u] = d;
                 m += d;
             }
             part[b] = m;
@@ -278,26 +280,21 @@ struct Clusterer {
 // generator's own communities: 8.13), reddit shape 672 -> 641 us (632; k = 32: 157 -> 152), flickr 38.0 -> 36.9, yelp 518 -> 517;
 // share of the edges within 2048 positions 0.20 -> 0.30 (0.34) on the amazon shape, 0.32 -> 0.45 (0.48) on reddit.  Stretch
 // length: 256 / 512 / 1024 / 2048 are the same on reddit (639-641 us) and amazon (8.26 / 8.25 ms at 512 / 1024); on the low-degree
-// shapes short stretches are noisy (yelp 538 / 524 / 517 / 513 us, flickr 38.0 / 37.5 / 36.9 / 36.9): 1024.  Costs 4 passes over the
-// edges (amazon shape: +0.65 s of planning).  Every decision of a sweep reads the labels of the sweep before: the result does
+// shapes short stretches are noisy (yelp 538 / 524 / 517 / 513 us, flickr 38.0 / 37.5 / 36.9 / 36.9): 1024.  Costs up to 4 passes over
+// the edges, long rows sampled (below): the same locality figures to three digits with every 1st, 2nd, 4th or 8th neighbour asked.  Every decision of a sweep reads the labels of the sweep before: the result does
 // not depend on the thread count.
-void refine_by_label_moves(int64_t n, const uint32_t *rowPtr, const uint32_t *col, std::vector<uint32_t> &rank) {
+void refine_by_label_moves(int64_t n, const uint32_t *rowPtr, const uint32_t *col, const std::vector<uint32_t> &deg, std::vector<uint32_t> &rank) {
     const int64_t env_stretch = std::getenv("FLEX_CLUSTER_STRETCH") ? std::atoll(std::getenv("FLEX_CLUSTER_STRETCH")) : 0;  // tuning experiments
     const int64_t kStretch = env_stretch >= 16 ? env_stretch : 1024;
-    constexpr int kSweeps = 4;
+    const int kSweeps = std::getenv("FLEX_CLUSTER_SWEEPS") ? std::atoi(std::getenv("FLEX_CLUSTER_SWEEPS")) : 4;
     if (n < 4 * kStretch) return;
     const uint32_t L = static_cast<uint32_t>((n + kStretch - 1) / kStretch);
-    std::vector<uint32_t> lab(static_cast<size_t>(n)), next(static_cast<size_t>(n)), deg(static_cast<size_t>(n));
+    std::vector<uint32_t> lab(static_cast<size_t>(n)), next(static_cast<size_t>(n));
     constexpr int64_t kBlk = 2048;  // vertices per work item
+    constexpr uint32_t kSampleFrom = 32;  // a row is sampled so that about this many of its entries (at least) are read
+    const uint32_t max_stride = std::getenv("FLEX_CLUSTER_STRIDE") ? static_cast<uint32_t>(std::max(1, std::atoi(std::getenv("FLEX_CLUSTER_STRIDE")))) : 4u;
     const int64_t nblk = (n + kBlk - 1) / kBlk;
-    parallel_chunks(nblk, [&](int64_t b) {
-        for (int64_t v = b * kBlk; v < std::min(n, (b + 1) * kBlk); ++v) {
-            uint32_t d = 0;
-            for (uint32_t e = rowPtr[v]; e < rowPtr[v + 1]; ++e) d += (col[e] != v);
-            deg[v] = d;
-            lab[v] = static_cast<uint32_t>(rank[v] / kStretch);
-        }
-    });
+    for (int64_t v = 0; v < n; ++v) lab[v] = static_cast<uint32_t>(rank[v] / kStretch);
     double M = 0;
     for (int64_t v = 0; v < n; ++v) M += deg[v];
     if (M <= 0) return;
@@ -318,20 +315,30 @@ void refine_by_label_moves(int64_t n, const uint32_t *rowPtr, const uint32_t *co
                 next[v] = cur;
                 if (deg[v] == 0) continue;
                 t.clear();
-                for (uint32_t e = rowPtr[v]; e < rowPtr[v + 1]; ++e) {
+                uint32_t same = 0;  // neighbours in v's own label: most of them, counted in a register (a[cur] += 1 per edge
+                                    // was one store-to-load chain through the whole row)
+                // A long row says the same thing many times over: every `stride`-th neighbour is asked (a different
+                // residue each sweep), and the counts are scaled back.  Rows of < 2 * kSampleFrom entries are read whole.
+                const uint32_t e_beg = rowPtr[v], e_end = rowPtr[v + 1];
+                const uint32_t stride = std::clamp<uint32_t>((e_end - e_beg) / kSampleFrom, 1u, max_stride);
+                for (uint32_t e = e_beg + static_cast<uint32_t>(sweep) % stride; e < e_end; e += stride) {
                     const uint32_t u = col[e];
-                    if (u == v) continue;
                     const uint32_t l = lab[u];
+                    if (l == cur) {
+                        same += (u != v);
+                        continue;
+                    }
                     if (a[l] == 0.f) t.push_back(l);
                     a[l] += 1.f;  // edge counts: exact in fp32
                 }
+                const double scale = stride;
                 const double dv = deg[v], dv_over_M = dv / M;
                 uint32_t best = cur;
-                double best_gain = static_cast<double>(a[cur]) - (D[cur] - dv) * dv_over_M;  // staying put
+                double best_gain = scale * same - (D[cur] - dv) * dv_over_M;  // staying put
                 for (uint32_t l : t) {
-                    const double g = static_cast<double>(a[l]) - D[l] * dv_over_M;
+                    const double g = scale * a[l] - D[l] * dv_over_M;
                     // ties: stay; between two other labels, the smaller id (the neighbours are met in CSR order, but so that nothing depends on it)
-                    if (l != cur && (g > best_gain || (g == best_gain && best != cur && l < best))) {
+                    if (g > best_gain || (g == best_gain && best != cur && l < best)) {
                         best_gain = g;
                         best = l;
                     }
@@ -387,7 +394,12 @@ int order_cluster_host(int64_t n, const uint32_t *rowPtr, const uint32_t *col, s
         Clusterer c(n, rowPtr, col);
         c.run(32);
         c.order(rank);
-        if (!std::getenv("FLEX_CLUSTER_NO_REFINE")) refine_by_label_moves(n, rowPtr, col, rank);
+        if (!std::getenv("FLEX_CLUSTER_NO_REFINE")) {
+            const auto t0 = std::chrono::steady_clock::now();
+            refine_by_label_moves(n, rowPtr, col, c.deg0, rank);
+            if (std::getenv("FLEX_PLAN_TIMING"))
+                std::fprintf(stderr, "cluster: vertex moves %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        }
     } catch (const std::bad_alloc &) {
         return FLEX_ERR_NOMEM;
     }
