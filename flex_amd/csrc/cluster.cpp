@@ -272,7 +272,8 @@ struct Clusterer {
 // The merge forest's depth-first order puts a community's members next to each other, but agglomeration never undoes a merge:
 // a vertex that joined a neighbour early stays with it even when most of its edges later turn out to lead elsewhere, and
 // two communities tied by many edges end up interleaved.  Here the order is cut into stretches of kStretch positions (labels),
-// and for a few synchronous sweeps every vertex moves to the label that holds most of its neighbours, priced like a modularity
+// and for a few synchronous sweeps (at most 8; until fewer than 3 % of the vertices move: 4 on the amazon shape, 6 on reddit)
+// every vertex moves to the label that holds most of its neighbours, priced like a modularity
 // move: gain(l) = w(v,l) - deg(v) * D(l) / M with D the label's total degree (its own degree taken out of the label it is in).
 // Labels empty out or grow to the size of the communities the graph really has; the new order is label by label in the order
 // of the labels' mean old position, members in their old order.
@@ -280,13 +281,13 @@ struct Clusterer {
 // generator's own communities: 8.13), reddit shape 672 -> 641 us (632; k = 32: 157 -> 152), flickr 38.0 -> 36.9, yelp 518 -> 517;
 // share of the edges within 2048 positions 0.20 -> 0.30 (0.34) on the amazon shape, 0.32 -> 0.45 (0.48) on reddit.  Stretch
 // length: 256 / 512 / 1024 / 2048 are the same on reddit (639-641 us) and amazon (8.26 / 8.25 ms at 512 / 1024); on the low-degree
-// shapes short stretches are noisy (yelp 538 / 524 / 517 / 513 us, flickr 38.0 / 37.5 / 36.9 / 36.9): 1024.  Costs up to 4 passes over
-// the edges, long rows sampled (below): the same locality figures to three digits with every 1st, 2nd, 4th or 8th neighbour asked.  Every decision of a sweep reads the labels of the sweep before: the result does
-// not depend on the thread count.
+// shapes short stretches are noisy (yelp 538 / 524 / 517 / 513 us, flickr 38.0 / 37.5 / 36.9 / 36.9): 1024.  The passes
+// over the edges read long rows sampled (below): the same locality figures to three digits with every 1st, 2nd, 4th or 8th
+// neighbour asked.  Every decision of a sweep reads the labels of the sweep before: the result does not depend on the thread count.
 void refine_by_label_moves(int64_t n, const uint32_t *rowPtr, const uint32_t *col, const std::vector<uint32_t> &deg, std::vector<uint32_t> &rank) {
     const int64_t env_stretch = std::getenv("FLEX_CLUSTER_STRETCH") ? std::atoll(std::getenv("FLEX_CLUSTER_STRETCH")) : 0;  // tuning experiments
     const int64_t kStretch = env_stretch >= 16 ? env_stretch : 1024;
-    const int kSweeps = std::getenv("FLEX_CLUSTER_SWEEPS") ? std::atoi(std::getenv("FLEX_CLUSTER_SWEEPS")) : 4;
+    const int kSweeps = std::getenv("FLEX_CLUSTER_SWEEPS") ? std::atoi(std::getenv("FLEX_CLUSTER_SWEEPS")) : 8;
     if (n < 4 * kStretch) return;
     const uint32_t L = static_cast<uint32_t>((n + kStretch - 1) / kStretch);
     std::vector<uint32_t> lab(static_cast<size_t>(n)), next(static_cast<size_t>(n));
@@ -352,7 +353,8 @@ void refine_by_label_moves(int64_t n, const uint32_t *rowPtr, const uint32_t *co
         lab.swap(next);
         int64_t moved = 0;
         for (int64_t m : moved_blk) moved += m;
-        if (moved * 256 < n) break;  // < 0.4 % of the vertices still want to move
+        if (std::getenv("FLEX_PLAN_TIMING")) std::fprintf(stderr, "cluster: sweep %d moved %lld of %lld\n", sweep + 1, static_cast<long long>(moved), static_cast<long long>(n));
+        if (moved * 100 < 3 * n) break;  // < 3 % of the vertices moved: what later sweeps add is within the noise of the launch time
     }
     // labels in the order of their members' mean old position; members keep their old order
     std::vector<double> sum_pos(L, 0.0);
