@@ -6,6 +6,10 @@
 //   plan_check.cpp    what is read back from a finished plan: self-check, statistics, measured imbalance
 #pragma once
 #include <cstdlib>
+#include <memory>
+#include <new>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "internal.h"
@@ -53,8 +57,28 @@ namespace flex {
 // A positive integer from the environment, or `dflt` (plan-time tuning knobs; nothing in the product sets them).
 long env_long(const char *name, long dflt);
 
+// std::vector<T>(n) zero-fills: for the record stream (8 B per nonzero) that is a single-threaded pass over gigabytes that
+// the parallel fill overwrites straight away.  With this allocator resize() leaves trivial elements uninitialised, and the
+// pages are first touched by the threads that fill them.
 template <typename T>
-int upload(T **dptr, const std::vector<T> &h, int64_t *bytes) {
+struct default_init_allocator : std::allocator<T> {
+    template <typename U>
+    struct rebind {
+        using other = default_init_allocator<U>;
+    };
+    template <typename U>
+    void construct(U *ptr) noexcept(std::is_nothrow_default_constructible_v<U>) {
+        ::new (static_cast<void *>(ptr)) U;
+    }
+    template <typename U, typename... Args>
+    void construct(U *ptr, Args &&...args) {
+        ::new (static_cast<void *>(ptr)) U(std::forward<Args>(args)...);
+    }
+};
+using RecordVec = std::vector<uint2, default_init_allocator<uint2>>;
+
+template <typename T, typename A>
+int upload(T **dptr, const std::vector<T, A> &h, int64_t *bytes) {
     *dptr = nullptr;
     const size_t nb = (h.empty() ? 1 : h.size()) * sizeof(T);
     FLEX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(dptr), nb));
@@ -100,6 +124,6 @@ int detect_dense_tiles(const flex_csr *A, int32_t r0, int32_t m, const std::vect
                        std::vector<uint8_t> &in_tile, DenseTiles &out);
 
 // ---- plan_check.cpp
-void collect_stats(flex_plan *p, const std::vector<uint2> &rec, const std::vector<uint4> &chunk, int64_t split_nnz);
+void collect_stats(flex_plan *p, const RecordVec &rec, const std::vector<uint4> &chunk, int64_t split_nnz);
 
 }  // namespace flex

@@ -123,7 +123,8 @@ class PlanBuilder {
     int64_t split_nnz = 0;
     // tasks, chunks, records
     std::vector<uint32_t> t_beg, t_dst, w_task;  // w_task[c] = first task of chunk c (+ sentinel)
-    std::vector<uint2> t_aux, rec;
+    std::vector<uint2> t_aux;
+    RecordVec rec;  // filled in parallel right after it is sized: no zero-fill pass (plan.h)
     uint32_t slice_chunk[kXcds + 1] = {0};  // 2-D: first chunk of each XCD slice
 
     void lap(const char *what) {

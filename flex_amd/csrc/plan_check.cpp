@@ -12,7 +12,7 @@ namespace flex {
 // ≙ alpha_stats_collect (mat.cu:944-1065): distinct B rows per chunk / workgroup / XCD slice by
 // stamping, and how evenly records are cut.  Padding records repeat the row's last column, so they
 // change no distinct count.
-void collect_stats(flex_plan *p, const std::vector<uint2> &rec, const std::vector<uint4> &chunk, int64_t split_nnz) {
+void collect_stats(flex_plan *p, const RecordVec &rec, const std::vector<uint4> &chunk, int64_t split_nnz) {
     flex_plan_stats &st = p->stats;
     st = flex_plan_stats{};
     const uint32_t n_chunks = static_cast<uint32_t>(chunk.size());
