@@ -225,6 +225,30 @@ def test_second_stage_of_the_community_order_moves_vertices_to_their_neighbours(
     assert np.array_equal(ranks[0], ranks[1]) and np.array_equal(ranks[0], ranks[2])
     assert sorted(ranks[0].tolist()) == list(range(g.n))
     assert near(ranks[0]) > near(walk) + 0.03, (near(ranks[0]), near(walk))
+    # a graph WITHOUT communities (R-MAT: labels would collapse around the hubs): the stage must notice and keep the walk's order
+    rng = np.random.default_rng(5)
+    scale, m_edges = 14, 16 << 14
+    r = np.zeros(m_edges, np.int64)
+    c = np.zeros(m_edges, np.int64)
+    for lvl in range(scale):
+        u = rng.random(m_edges)
+        r |= (u >= 0.76).astype(np.int64) << lvl
+        c |= (((u >= 0.57) & (u < 0.76)) | (u >= 0.95)).astype(np.int64) << lvl
+    perm = rng.permutation(1 << scale)
+    key = np.unique(np.concatenate([perm[r] * (1 << scale) + perm[c], perm[c] * (1 << scale) + perm[r], np.arange(1 << scale) * ((1 << scale) + 1)]))
+    rr, cc = key >> scale, key & ((1 << scale) - 1)
+    rp = np.zeros((1 << scale) + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rr, minlength=1 << scale), out=rp[1:])
+    rmat = flex_amd.HostCsr(rp.astype(np.uint32), cc.astype(np.uint32), np.ones(len(cc), np.float32), n=1 << scale)
+    monkeypatch.setenv("FLEX_CLUSTER_NO_REFINE", "1")
+    walk_rmat = flex_amd.order_cluster(rmat)
+    monkeypatch.delenv("FLEX_CLUSTER_NO_REFINE")
+    rows_rmat = np.repeat(np.arange(rmat.m), np.diff(rp))
+    staged = flex_amd.order_cluster(rmat)
+
+    def near_rmat(rank, w=2048):
+        return float(np.mean(np.abs(rank[rows_rmat].astype(np.int64) - rank[rmat.col].astype(np.int64)) <= w))
+    assert sorted(staged.tolist()) == list(range(rmat.m)) and near_rmat(staged) >= 0.98 * near_rmat(walk_rmat)
     # too small to cut into stretches: the walk's order is kept as it is
     small = flex_amd.synth_graph(n=3000, nnz=3000 + 2 * 20000, community=50, p_in=0.5, p_near=0.2, seed=1)
     r1 = flex_amd.order_cluster(small)
