@@ -281,6 +281,7 @@ def order_rcm(a: HostCsr) -> np.ndarray:
 
 
 def order_cluster(a: HostCsr) -> np.ndarray:
+    """The engine's community order (agglomeration + vertex moves, cluster.cpp): rank[old] = new."""
     rank = np.empty(max(a.m, 1), dtype=np.uint32)
     v = a.view()
     _check(lib().flex_order_cluster(C.byref(v), rank.ctypes.data), "flex_order_cluster")

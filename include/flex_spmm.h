@@ -307,7 +307,9 @@ int flex_order_rabbit(const flex_csr *A, int is_directed, uint32_t *rank);
 int flex_order_deg(const flex_csr *A, int descending, uint32_t *rank);
 
 /* ≙ the clustering half of DataLoaderRabbit (DataLoader.cu:453-655): rank[old] = new such
- * that communities (and their sub-communities) are consecutive. */
+ * that communities (and their sub-communities) are consecutive.  Two stages (cluster.cpp): modularity-driven agglomeration
+ * + a walk of the merge forest, then a few sweeps of vertex moves between stretches of that order (kept only when they
+ * put more edges within 2048 positions).  Deterministic: the same rank for any number of host threads. */
 int flex_order_cluster(const flex_csr *A, uint32_t *rank);
 
 /* ≙ DataLoaderRcm body (DataLoader.cu:741-779): vo_mp[new]=old + permuted CSR, columns
