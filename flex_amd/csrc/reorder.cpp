@@ -8,11 +8,13 @@
 // straight from the CSR, the degree order is a counting sort, and neighbour
 // lists are built already sorted by scattering in relabelled order.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <numeric>
 #include <stdexcept>
 #include <vector>
 
+#include "host_parallel.h"
 #include "internal.h"
 
 namespace flex {
@@ -176,18 +178,28 @@ int flex_perm_csr(const flex_csr *A, const uint32_t *rank, int32_t *vo_mp, uint3
     }
     rowPtr2[0] = 0;
     for (int32_t i = 0; i < n; ++i) rowPtr2[i + 1] = rowPtr2[i] + (A->rowPtr[vo_mp[i] + 1] - A->rowPtr[vo_mp[i]]);
-    std::vector<std::pair<uint32_t, float>> row;
-    for (int32_t s = 0; s < n; ++s) {  // DataLoader.cu:758-779: map columns, sort ascending
-        row.clear();
-        for (uint32_t e = A->rowPtr[s]; e < A->rowPtr[s + 1]; ++e) row.emplace_back(rank[A->col[e]], A->vals[e]);
-        std::sort(row.begin(), row.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
-        uint32_t o = rowPtr2[rank[s]];
-        for (const auto &cv : row) {
-            col2[o] = cv.first;
-            vals2[o++] = cv.second;
+    // DataLoader.cu:758-779: map columns, sort ascending.  Rows are independent (each owns its output range): blocks of rows
+    // in parallel -- the amazon shape spent 6.5 s here on one thread, every rank of a row-sharded run pays it.
+    constexpr int64_t kBlk = 4096;
+    std::atomic<int> failed{0};
+    flex::parallel_chunks((static_cast<int64_t>(n) + kBlk - 1) / kBlk, [&](int64_t b) {
+        try {
+            std::vector<std::pair<uint32_t, float>> row;
+            for (int64_t s = b * kBlk; s < std::min<int64_t>(n, (b + 1) * kBlk); ++s) {
+                row.clear();
+                for (uint32_t e = A->rowPtr[s]; e < A->rowPtr[s + 1]; ++e) row.emplace_back(rank[A->col[e]], A->vals[e]);
+                std::sort(row.begin(), row.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+                uint32_t o = rowPtr2[rank[s]];
+                for (const auto &cv : row) {
+                    col2[o] = cv.first;
+                    vals2[o++] = cv.second;
+                }
+            }
+        } catch (...) {
+            failed.store(1);
         }
-    }
-    return FLEX_OK;
+    });
+    return failed.load() ? FLEX_ERR_NOMEM : FLEX_OK;
 } catch (const std::bad_alloc &) {
     return FLEX_ERR_NOMEM;
 } catch (const std::length_error &) {
