@@ -30,7 +30,7 @@ steps = 5 if a.nnz > 100_000_000 else 30
 
 
 def run(env):
-    for key in ("FLEX_2D", "FLEX_PANEL_KB", "FLEX_SEG_MIN", "FLEX_LANES", "FLEX_WAVE_NNZ", "FLEX_FUSED_FIXUP", "FLEX_REC_NT", "FLEX_U", "FLEX_MFMA", "FLEX_LONG_ROW", "FLEX_PIECE", "FLEX_MFMA_FILL"):
+    for key in [k_ for k_ in os.environ if k_.startswith("FLEX_") and k_ != "FLEX_HOST_THREADS"]:  # every plan-time knob, whatever the variant before set
         os.environ.pop(key, None)
     os.environ.update({k_: str(v) for k_, v in env.items()})
     t0 = time.perf_counter()
