@@ -42,7 +42,9 @@ extern "C" int flex_order_rabbit(const flex_csr *A, int is_directed, uint32_t *r
     const uint32_t n = static_cast<uint32_t>(A->m);
     if (n == 0) return FLEX_OK;
     std::vector<NbrList> g(n);
-    for (uint32_t v = 0; v < n; ++v)
+    std::vector<int64_t> deg(n);
+    int64_t n_edges = 0;
+    for (uint32_t v = 0; v < n; ++v) {
         for (uint32_t e = A->rowPtr[v]; e < A->rowPtr[v + 1]; ++e) {
             const uint32_t d = A->col[e];
             if (d == v) continue;
@@ -53,9 +55,10 @@ extern "C" int flex_order_rabbit(const flex_csr *A, int is_directed, uint32_t *r
                 if (jt == g[d].end() || jt->v != v) g[d].insert(jt, Nbr{v, 1});
             }
         }
-    std::vector<int64_t> deg(n);
-    int64_t n_edges = 0;
-    for (uint32_t v = 0; v < n; ++v) n_edges += (deg[v] = static_cast<int64_t>(g[v].size()));
+        // the reference takes a vertex's degree at the END OF ITS OWN TURN here (DataLoader.cu:529-530): its out-edges plus the
+        // reverse edges inserted by the vertices before it; reverse edges that later vertices add reach the map, not deg / n_edges
+        n_edges += (deg[v] = static_cast<int64_t>(g[v].size()));
+    }
     const double two_m_inv = 1.0 / static_cast<double>(2 * n_edges);
     // dendrogram: ids < n are leaves; n + u is the node created when u was merged away: (tree of its target, tree of u)
     std::vector<int64_t> left(2 * static_cast<size_t>(n), -1), right(2 * static_cast<size_t>(n), -1), tree(n);

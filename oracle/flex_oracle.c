@@ -707,7 +707,8 @@ int oracle_order_dfs(int64_t n, const uint32_t *rowPtr, const uint32_t *col, uin
  * opt_hub_group = opt_hub_sort = false, cluster shyness 1): modularity-driven agglomeration in rounds.
  *   - every vertex keeps a map neighbour -> weight (std::map<int,int> dst_wht: iteration in ascending key); weight 1 per
  *     distinct neighbour, self loops left out, and for a directed graph (dl.is_directed) the reverse edge is added too
- *     (force_undirected, :516-531); deg = number of distinct neighbours, n_edges = sum of deg, two_m_inv = 1/(2 n_edges);
+ *     (force_undirected, :516-531); deg = size of the map when the vertex's turn in the construction loop ends (:529), n_edges =
+ *     sum of deg, two_m_inv = 1/(2 n_edges);
  *   - round: vertices of the round sorted by current deg (:545-546); u is skipped if it absorbed something this round
  *     (:554); its target is the neighbour with the largest  w - deg[d] * deg[u] * two_m_inv,  first maximum in ascending
  *     d (set_max is a strict >, common.h:101-107; start value -1), and only if that is > 0 (:556-560);
@@ -763,7 +764,8 @@ int oracle_order_rabbit(int64_t n, const uint32_t *rowPtr, const uint32_t *col, 
     int64_t *stack = (int64_t *)malloc(sizeof(int64_t) * (2 * (size_t)n + 2));
     if (!g || !deg || !round_of || !lch || !rch || !tree || !cur || !nxt || !tmp || !stack) return -ENOMEM;
     int rc = 0;
-    for (int64_t v = 0; v < n && !rc; ++v)
+    int64_t n_edges = 0;
+    for (int64_t v = 0; v < n && !rc; ++v) {
         for (uint32_t e = rowPtr[v]; e < rowPtr[v + 1] && !rc; ++e) {
             const uint32_t d = col[e];
             if (d == (uint32_t)v) continue;
@@ -771,10 +773,13 @@ int oracle_order_rabbit(int64_t n, const uint32_t *rowPtr, const uint32_t *col, 
             if (i < 0) rc = rb_add(&g[v], d, 1); /* dst_wht[d] = 1 (an assignment: duplicates do not add up) */
             if (is_directed && !rc && rb_find(&g[d], (uint32_t)v) < 0) rc = rb_add(&g[d], (uint32_t)v, 1);
         }
-    int64_t n_edges = 0;
-    for (int64_t v = 0; v < n; ++v) {
+        /* vo.deg = vo.dst_wht.size() INSIDE the construction loop (:529-530): v's own edges plus the reverse edges that the
+         * vertices before it inserted -- for a directed graph the reverse edges of later vertices are in the map by the
+         * time the rounds start, but never in deg / n_edges.  Symmetric inputs are unaffected. */
         deg[v] = g[v].n;
         n_edges += deg[v];
+    }
+    for (int64_t v = 0; v < n; ++v) {
         tree[v] = v;
         lch[v] = rch[v] = -1;
         cur[v] = (uint32_t)v;

@@ -292,6 +292,15 @@ def test_rabbit_order_equals_oracle_restatement():
     # isolated vertices, a self loop, a duplicate entry: they keep their place in index order
     odd = flex_amd.HostCsr([0, 2, 4, 5, 5, 6], [1, 1, 0, 0, 2, 4], [1, 1, 1, 1, 1, 1])
     assert np.array_equal(flex_amd.order_rabbit(odd, False).astype(np.uint64), oracle.order_rabbit(odd.rowPtr, odd.col, False))
+    # directed and asymmetric, expected rank derived BY HAND from the reference's rule (DataLoader.cu:515-531: a vertex's degree is
+    # the size of its map at the end of its own turn in the construction loop, so reverse edges inserted by LATER vertices
+    # count in the map but not in deg / n_edges).  Edges 0->1, 3->0, 3->1, 3->2: deg = [1,1,0,3], n_edges = 5.
+    #   round 1 (by deg: 2,0,1,3): 2 joins 3 (gain 1); 0 joins 1 (0.9 against 0.7 for 3); 1 and 3 absorbed something: skipped
+    #   round 2 (1: deg 2, 3: deg 3): 1 joins 3 (gain 2 - 3*2/10); dendrogram ((3,2),(1,0)) -> order 3,2,1,0
+    # With degrees taken after the full symmetrisation ([2,2,1,3], n_edges 8) round 2 would tie at deg 4 and 3 would join 1: 1,0,3,2.
+    asym = flex_amd.HostCsr([0, 1, 1, 1, 4], [1, 0, 1, 2], [1, 1, 1, 1])
+    assert flex_amd.order_rabbit(asym, True).tolist() == [3, 2, 1, 0]
+    assert oracle.order_rabbit(asym.rowPtr, asym.col, True).tolist() == [3, 2, 1, 0]
     # locality: on a shuffled community graph the order pulls neighbours together
     g = cases[2]
     rows = np.repeat(np.arange(g.m), np.diff(g.rowPtr.astype(np.int64)))
