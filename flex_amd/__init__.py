@@ -40,6 +40,7 @@ from .binding import (  # noqa: F401
     order_rabbit,
     synth_preset,
     perm_csr,
+    set_host_threads,
     shard_rows,
     synth_graph,
     SYNTH_PRESETS,

@@ -66,10 +66,45 @@ class _PlanStats(C.Structure):  # flex_plan_stats
                 ("tile_mean_fill", C.c_double), ("mfma_tiles", C.c_int64), ("mfma_nnz_pct", C.c_double)]
 
 
+class _ClusterTuning(C.Structure):  # flex_cluster_tuning
+    _fields_ = [(f, C.c_int32) for f in ("batch", "no_refine", "stretch", "sweeps", "stride")]
+
+
+class _PlanTuning(C.Structure):  # flex_plan_tuning: every field 0 = the planner's rule
+    _fields_ = [(f, C.c_int32) for f in (
+        "lanes_per_nz", "chunk_records", "long_row", "piece_records", "row_cost", "xcd_slices", "xcd_balance",
+        "chunk_cost", "task_cost", "split_rows", "rec_nt", "unroll", "two_d", "panel_kb", "seg_min", "mfma",
+        "mfma_fill_pct", "lds_extra", "host_threads")] + [("cluster", _ClusterTuning), ("reserved", C.c_int32 * 16)]
+
+
+TUNING_FIELDS = tuple(f for f, _ in _PlanTuning._fields_ if f not in ("cluster", "reserved"))
+CLUSTER_TUNING_FIELDS = tuple(f for f, _ in _ClusterTuning._fields_)
+
+
+# Knobs applied to every Plan() of this PROCESS that does not name them itself: a convenience of this binding for tests and
+# tools whose plans are created inside helpers (the library has no such state: it only sees the descriptor it is handed).
+DEFAULT_TUNING: dict = {}
+
+
+def _tuning(d) -> "_PlanTuning | None":
+    """dict -> flex_plan_tuning; keys are its field names, cluster knobs as cluster_<field> (cluster_no_refine=1 ...)."""
+    if not d:
+        return None
+    t = _PlanTuning()
+    for key, val in d.items():
+        if key in TUNING_FIELDS:
+            setattr(t, key, int(val))
+        elif key.startswith("cluster_") and key[8:] in CLUSTER_TUNING_FIELDS:
+            setattr(t.cluster, key[8:], int(val))
+        else:
+            raise FlexError(f"unknown tuning knob {key!r} (flex_plan_tuning has: {', '.join(TUNING_FIELDS)}, cluster_*)")
+    return t
+
+
 class _PlanDesc(C.Structure):  # flex_plan_desc
     _fields_ = [("struct_size", C.c_size_t), ("A", C.POINTER(_Csr)), ("k", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int),
                 ("device", C.c_int), ("flags", C.c_uint), ("row_begin", C.c_int64), ("row_end", C.c_int64),
-                ("col_map", C.c_void_p), ("row_map", C.c_void_p)]
+                ("col_map", C.c_void_p), ("row_map", C.c_void_p), ("tuning", C.POINTER(_PlanTuning))]
 
 
 class _KernelInfo(C.Structure):  # flex_kernel_info
@@ -93,7 +128,7 @@ class _SynthParams(C.Structure):  # flex_synth_params
 # every symbol include/flex_spmm.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = [
     "flex_plan_create", "flex_plan_create_ex", "flex_plan_create_ld", "flex_plan_create_mapped", "flex_plan_create_rows", "flex_spmm",
-    "flex_plan_destroy", "flex_plan_measure_imbalance", "flex_plan_get_info", "flex_plan_get_stats", "flex_plan_self_check", "flex_plan_kernel_info", "flex_hbm_probe", "flex_gather_rows", "flex_csv_load", "flex_mtx_load",
+    "flex_plan_destroy", "flex_plan_measure_imbalance", "flex_plan_get_info", "flex_plan_get_stats", "flex_plan_get_tuning", "flex_set_host_threads", "flex_order_cluster_ex", "flex_plan_self_check", "flex_plan_kernel_info", "flex_hbm_probe", "flex_gather_rows", "flex_csv_load", "flex_mtx_load",
     "flex_csv_save", "flex_csr_save_bin", "flex_csr_load_bin", "flex_csr_fingerprint", "flex_perm_save", "flex_perm_load",
     "flex_host_csr_free", "flex_fill_dense_rand", "flex_order_rcm", "flex_order_cluster", "flex_order_gorder", "flex_perm_csr",
     "flex_order_deg", "flex_order_dfs", "flex_order_rabbit", "flex_shard_rows", "flex_synth_graph", "flex_synth_preset", "flex_strerror", "flex_last_hip_error",
@@ -140,6 +175,9 @@ def lib():
         L.flex_plan_destroy.argtypes = [vp]
         L.flex_plan_get_info.argtypes = [vp, C.POINTER(_PlanInfo)]
         L.flex_plan_get_stats.argtypes = [vp, C.POINTER(_PlanStats)]
+        L.flex_plan_get_tuning.argtypes = [vp, C.POINTER(_PlanTuning)]
+        L.flex_set_host_threads.argtypes = [i32]
+        L.flex_order_cluster_ex.argtypes = [C.POINTER(_Csr), C.POINTER(_ClusterTuning), vp]
         L.flex_plan_self_check.argtypes = [vp]
         L.flex_plan_measure_imbalance.argtypes = [vp, vp, vp, vp, C.POINTER(_Imbalance)]
         L.flex_plan_kernel_info.argtypes = [vp, C.POINTER(_KernelInfo)]
@@ -280,12 +318,23 @@ def order_rcm(a: HostCsr) -> np.ndarray:
     return rank[: a.m]
 
 
-def order_cluster(a: HostCsr) -> np.ndarray:
-    """The engine's community order (agglomeration + vertex moves, cluster.cpp): rank[old] = new."""
+def order_cluster(a: HostCsr, **knobs) -> np.ndarray:
+    """The engine's community order (agglomeration + vertex moves, cluster.cpp): rank[old] = new.
+    knobs: fields of flex_cluster_tuning (batch, no_refine, stretch, sweeps, stride)."""
     rank = np.empty(max(a.m, 1), dtype=np.uint32)
     v = a.view()
-    _check(lib().flex_order_cluster(C.byref(v), rank.ctypes.data), "flex_order_cluster")
+    t = _ClusterTuning()
+    for key, val in knobs.items():
+        if key not in CLUSTER_TUNING_FIELDS:
+            raise FlexError(f"unknown cluster knob {key!r}")
+        setattr(t, key, int(val))
+    _check(lib().flex_order_cluster_ex(C.byref(v), C.byref(t), rank.ctypes.data), "flex_order_cluster_ex")
     return rank[: a.m]
+
+
+def set_host_threads(n: int) -> int:
+    """Process-wide cap on the planner's / orderings' / generator's worker threads (0 = core count); returns the old value."""
+    return int(lib().flex_set_host_threads(int(n)))
 
 
 def perm_csr(a: HostCsr, rank: np.ndarray):
@@ -366,12 +415,15 @@ class Plan:
     """flex_plan handle (≙ Mat after csr2_DiagTiling + alpha_transfer)."""
 
     def __init__(self, a: HostCsr, k: int, device: int = 0, order: int = FLEX_ORDER_NATURAL,
-                 vo_mp=None, rows=None, col_map=None, ldb: int | None = None, ldc: int | None = None):
+                 vo_mp=None, rows=None, col_map=None, ldb: int | None = None, ldc: int | None = None, tuning: dict | None = None):
+        """tuning: plan-time knobs as a dict of flex_plan_tuning fields (0 / absent = the planner's rule), e.g.
+        {"lanes_per_nz": 16, "split_rows": 1, "cluster_no_refine": 1}."""
         self._h = C.c_void_p()
         self._keep = (a, vo_mp, col_map)
         v = a.view()
         L = lib()
-        if (ldb is not None or ldc is not None) and (rows is not None or vo_mp is not None):
+        tn = _tuning({**DEFAULT_TUNING, **(tuning or {})})
+        if tn is not None or ((ldb is not None or ldc is not None) and (rows is not None or vo_mp is not None)):
             # a combination the named entry points do not cover: the general one
             cm = None if col_map is None else np.ascontiguousarray(col_map, dtype=np.int32)
             vm = None if vo_mp is None else np.ascontiguousarray(vo_mp, dtype=np.int32)
@@ -380,7 +432,7 @@ class Plan:
                           order | (0 if rows is None else FLEX_PLAN_ROW_RANGE),
                           0 if rows is None else int(rows[0]), 0 if rows is None else int(rows[1]),
                           (cm if cm is not None else vm).ctypes.data if (cm is not None or vm is not None) else None,
-                          None if vm is None else vm.ctypes.data)
+                          None if vm is None else vm.ctypes.data, None if tn is None else C.pointer(tn))
             rc = L.flex_plan_create_ex(C.byref(self._h), C.byref(d))
         elif rows is not None:
             cm = None if col_map is None else np.ascontiguousarray(col_map, dtype=np.int32)
@@ -408,6 +460,14 @@ class Plan:
         st = _PlanStats()
         _check(lib().flex_plan_get_stats(self._h, C.byref(st)), "flex_plan_get_stats")
         return {f: getattr(st, f) for f, _ in _PlanStats._fields_}
+
+    def tuning(self) -> dict:
+        """flex_plan_get_tuning: the knobs this plan was built with, rules resolved."""
+        t = _PlanTuning()
+        _check(lib().flex_plan_get_tuning(self._h, C.byref(t)), "flex_plan_get_tuning")
+        d = {f: getattr(t, f) for f in TUNING_FIELDS}
+        d.update({"cluster_" + f: getattr(t.cluster, f) for f in CLUSTER_TUNING_FIELDS})
+        return d
 
     def kernel_info(self) -> dict:
         ki = _KernelInfo()

@@ -4,7 +4,6 @@
 #include <hip/hip_runtime.h>
 #include <rocblas/rocblas.h>
 
-#include <cstdlib>
 #include <new>
 
 #include "../../include/flex_axw.h"
@@ -15,7 +14,7 @@ extern "C" hipError_t flex_axw_gemm_launch(const float *L, const float *Wp, floa
 struct flex_axw {
     int32_t n = 0;
     int n_cus = 0;
-    bool use_blas = false;  // FLEX_AXW_BLAS=1, or a shape the MFMA kernel does not take (dim % 4 != 0, dim > 256, n < 32)
+    bool use_blas = false;  // FLEX_AXW_USE_BLAS in `flags`, or a shape the MFMA kernel does not take (dim % 4 != 0, dim > 256, n < 32)
     int dim = 0, c = 0, cp = 0, device = 0;
     flex_plan *plan_c = nullptr, *plan_dim = nullptr;
     float *d_xw = nullptr;  // n x cp
@@ -85,6 +84,8 @@ int flex_axw_create(flex_axw **out, const flex_csr *A, int dim, int c, int devic
     int prev = -1;
     (void)hipGetDevice(&prev);
     int rc = hip_fail(hipSetDevice(device));
+    const bool want_blas = (flags & FLEX_AXW_USE_BLAS) != 0;
+    flags &= ~FLEX_AXW_USE_BLAS;
     if (!rc) rc = flex_plan_create(&h->plan_c, A, h->cp, device, flags);
     if (!rc) rc = flex_plan_create(&h->plan_dim, A, dim, device, flags);
     const size_t n1 = static_cast<size_t>(h->n > 0 ? h->n : 1);
@@ -98,8 +99,7 @@ int flex_axw_create(flex_axw **out, const flex_csr *A, int dim, int c, int devic
         hipDeviceProp_t prop;
         rc = hip_fail(hipGetDeviceProperties(&prop, device));
         h->n_cus = prop.multiProcessorCount;
-        const char *e = std::getenv("FLEX_AXW_BLAS");
-        h->use_blas = (e && *e == '1') || dim % 4 != 0 || dim > 256 || h->n < 32;
+        h->use_blas = want_blas || dim % 4 != 0 || dim > 256 || h->n < 32;
     }
     if (prev >= 0) (void)hipSetDevice(prev);
     if (rc) {

@@ -41,6 +41,7 @@ struct Clusterer {
     std::vector<std::vector<uint32_t>> rawm;                      // + the vertices absorbed in that state: their CSR rows are read in place
     std::vector<std::vector<uint32_t>> children;                  // merge forest
     double M = 0;                                                 // total degree (2m)
+    int64_t batch = 4096;                                         // proposals per batch (flex_cluster_tuning.batch)
 
     Clusterer(int64_t n_, const uint32_t *rp, const uint32_t *c)
         : n(n_), rowPtr(rp), col(c), parent(n_), cdeg(n_, 0.0), deg0(n_), adj(n_), segs(n_), raw(n_, 1), rawm(n_), children(n_) {
@@ -143,8 +144,8 @@ struct Clusterer {
         std::iota(cur.begin(), cur.end(), 0u);
         std::vector<uint32_t> stamp(static_cast<size_t>(n), 0u);
         std::vector<std::pair<uint32_t, uint32_t>> moved;  // (new root, absorbed community) of the current batch, in the order decided
-        const int64_t env_batch = std::getenv("FLEX_CLUSTER_BATCH") ? std::atoll(std::getenv("FLEX_CLUSTER_BATCH")) : 4096;
-        const bool timing = std::getenv("FLEX_PLAN_TIMING") != nullptr;
+        const int64_t env_batch = batch;
+        const bool timing = plan_timing_enabled();
         double t_sort = 0, t_a = 0, t_b = 0, t_c = 0;
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto secs = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
@@ -306,16 +307,16 @@ int64_t edges_within(int64_t n, const uint32_t *rowPtr, const uint32_t *col, con
     return total;
 }
 
-void refine_by_label_moves(int64_t n, const uint32_t *rowPtr, const uint32_t *col, const std::vector<uint32_t> &deg, std::vector<uint32_t> &rank) {
-    const int64_t env_stretch = std::getenv("FLEX_CLUSTER_STRETCH") ? std::atoll(std::getenv("FLEX_CLUSTER_STRETCH")) : 0;  // tuning experiments
-    const int64_t kStretch = env_stretch >= 16 ? env_stretch : 1024;
-    const int kSweeps = std::getenv("FLEX_CLUSTER_SWEEPS") ? std::atoi(std::getenv("FLEX_CLUSTER_SWEEPS")) : 8;
+void refine_by_label_moves(int64_t n, const uint32_t *rowPtr, const uint32_t *col, const std::vector<uint32_t> &deg, std::vector<uint32_t> &rank,
+                           const flex_cluster_tuning &tn) {
+    const int64_t kStretch = tn.stretch >= 16 ? tn.stretch : 1024;  // tuning experiments
+    const int kSweeps = tn.sweeps > 0 ? tn.sweeps : 8;
     if (n < 4 * kStretch) return;
     const uint32_t L = static_cast<uint32_t>((n + kStretch - 1) / kStretch);
     std::vector<uint32_t> lab(static_cast<size_t>(n)), next(static_cast<size_t>(n));
     constexpr int64_t kBlk = 2048;  // vertices per work item
     constexpr uint32_t kSampleFrom = 32;  // a row is sampled so that about this many of its entries (at least) are read
-    const uint32_t max_stride = std::getenv("FLEX_CLUSTER_STRIDE") ? static_cast<uint32_t>(std::max(1, std::atoi(std::getenv("FLEX_CLUSTER_STRIDE")))) : 4u;
+    const uint32_t max_stride = tn.stride > 0 ? static_cast<uint32_t>(tn.stride) : 4u;
     const int64_t nblk = (n + kBlk - 1) / kBlk;
     for (int64_t v = 0; v < n; ++v) lab[v] = static_cast<uint32_t>(rank[v] / kStretch);
     double M = 0;
@@ -376,7 +377,7 @@ void refine_by_label_moves(int64_t n, const uint32_t *rowPtr, const uint32_t *co
         lab.swap(next);
         int64_t moved = 0;
         for (int64_t m : moved_blk) moved += m;
-        if (std::getenv("FLEX_PLAN_TIMING")) std::fprintf(stderr, "cluster: sweep %d moved %lld of %lld\n", sweep + 1, static_cast<long long>(moved), static_cast<long long>(n));
+        if (plan_timing_enabled()) std::fprintf(stderr, "cluster: sweep %d moved %lld of %lld\n", sweep + 1, static_cast<long long>(moved), static_cast<long long>(n));
         if (moved * 100 < 3 * n) break;  // < 3 % of the vertices moved: what later sweeps add is within the noise of the launch time
         if (sweep > 0 && moved > prev_moved) return;  // more moves than the sweep before: the labels are chasing hubs, not settling (R-MAT): keep the walk's order
         prev_moved = moved;
@@ -413,13 +414,14 @@ void refine_by_label_moves(int64_t n, const uint32_t *rowPtr, const uint32_t *co
     // it is better than the walk's by a margin.
     constexpr uint32_t kWindow = 2048;
     const int64_t before = edges_within(n, rowPtr, col, rank, kWindow), after = edges_within(n, rowPtr, col, moved_rank, kWindow);
-    if (std::getenv("FLEX_PLAN_TIMING")) std::fprintf(stderr, "cluster: (sampled) edges within %u positions: %lld -> %lld\n", kWindow, static_cast<long long>(before), static_cast<long long>(after));
+    if (plan_timing_enabled()) std::fprintf(stderr, "cluster: (sampled) edges within %u positions: %lld -> %lld\n", kWindow, static_cast<long long>(before), static_cast<long long>(after));
     if (after * 100 > before * 102) rank.swap(moved_rank);
 }
 
 }  // namespace
 
-int order_cluster_host(int64_t n, const uint32_t *rowPtr, const uint32_t *col, std::vector<uint32_t> &rank) {
+int order_cluster_host(int64_t n, const uint32_t *rowPtr, const uint32_t *col, std::vector<uint32_t> &rank, const flex_cluster_tuning *tuning) {
+    const flex_cluster_tuning tn = tuning ? *tuning : flex_cluster_tuning{};
     if (n == 0) {
         rank.clear();
         return FLEX_OK;
@@ -428,12 +430,13 @@ int order_cluster_host(int64_t n, const uint32_t *rowPtr, const uint32_t *col, s
         if (col[e] >= n) return FLEX_ERR_INVALID;
     try {
         Clusterer c(n, rowPtr, col);
+        if (tn.batch > 0) c.batch = tn.batch;
         c.run(32);
         c.order(rank);
-        if (!std::getenv("FLEX_CLUSTER_NO_REFINE")) {
+        if (!tn.no_refine) {
             const auto t0 = std::chrono::steady_clock::now();
-            refine_by_label_moves(n, rowPtr, col, c.deg0, rank);
-            if (std::getenv("FLEX_PLAN_TIMING"))
+            refine_by_label_moves(n, rowPtr, col, c.deg0, rank, tn);
+            if (plan_timing_enabled())
                 std::fprintf(stderr, "cluster: vertex moves %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         }
     } catch (const std::bad_alloc &) {
@@ -444,13 +447,16 @@ int order_cluster_host(int64_t n, const uint32_t *rowPtr, const uint32_t *col, s
 
 }  // namespace flex
 
-extern "C" int flex_order_cluster(const flex_csr *A, uint32_t *rank) try {
+extern "C" int flex_order_cluster(const flex_csr *A, uint32_t *rank) { return flex_order_cluster_ex(A, nullptr, rank); }
+
+extern "C" int flex_order_cluster_ex(const flex_csr *A, const flex_cluster_tuning *tuning, uint32_t *rank) try {
     if (!rank) return FLEX_ERR_INVALID;
+    if (tuning && (tuning->batch < 0 || tuning->no_refine < 0 || tuning->stretch < 0 || tuning->sweeps < 0 || tuning->stride < 0)) return FLEX_ERR_INVALID;
     int rc = flex::validate_csr(A);
     if (rc) return rc;
     if (A->m != A->n) return FLEX_ERR_INVALID;
     std::vector<uint32_t> r;
-    rc = flex::order_cluster_host(A->m, A->rowPtr, A->col, r);
+    rc = flex::order_cluster_host(A->m, A->rowPtr, A->col, r, tuning);
     if (rc) return rc;
     std::copy(r.begin(), r.end(), rank);
     return FLEX_OK;

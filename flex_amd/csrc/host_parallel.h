@@ -8,17 +8,58 @@
 #include <mutex>
 #include <cstdint>
 #include <cstdlib>
+#include <exception>
 #include <thread>
 #include <vector>
 
 namespace flex {
 
+// How many threads a parallel section started by THIS thread may use: the caller's own setting for the duration of one
+// ABI call (flex_plan_tuning.host_threads, HostThreadsScope), else the process-wide cap (flex_set_host_threads), else the
+// core count; at most 32.  Results never depend on it.
+inline std::atomic<int> &host_threads_cap() {
+    static std::atomic<int> cap{0};
+    return cap;
+}
+inline int &host_threads_here() {
+    static thread_local int n = 0;
+    return n;
+}
 inline int host_threads() {
-    long t = 0;
-    if (const char *e = std::getenv("FLEX_HOST_THREADS")) t = std::strtol(e, nullptr, 10);
+    long t = host_threads_here();
+    if (t <= 0) t = host_threads_cap().load(std::memory_order_relaxed);
     if (t <= 0) t = static_cast<long>(std::thread::hardware_concurrency());
     return static_cast<int>(std::clamp<long>(t, 1, 32));
 }
+struct HostThreadsScope {  // sets the calling thread's count for one ABI call
+    int saved;
+    explicit HostThreadsScope(int n) : saved(host_threads_here()) {
+        if (n > 0) host_threads_here() = n;
+    }
+    ~HostThreadsScope() { host_threads_here() = saved; }
+    HostThreadsScope(const HostThreadsScope &) = delete;
+    HostThreadsScope &operator=(const HostThreadsScope &) = delete;
+};
+
+// The first exception thrown by any chunk of a parallel section (a std::bad_alloc in a worker would otherwise reach
+// std::terminate): the section stops handing out chunks, every thread is joined, and the caller rethrows it.
+class FirstError {
+   public:
+    void capture() noexcept {
+        std::lock_guard<std::mutex> lk(m_);
+        if (!e_) e_ = std::current_exception();
+        set_.store(true, std::memory_order_release);
+    }
+    bool set() const noexcept { return set_.load(std::memory_order_acquire); }
+    void rethrow() {
+        if (e_) std::rethrow_exception(e_);
+    }
+
+   private:
+    std::mutex m_;
+    std::exception_ptr e_;
+    std::atomic<bool> set_{false};
+};
 
 template <typename F>
 void parallel_chunks(int64_t nchunks, F &&fn) {
@@ -28,13 +69,24 @@ void parallel_chunks(int64_t nchunks, F &&fn) {
         return;
     }
     std::atomic<int64_t> next{0};
+    FirstError err;
+    auto body = [&] {
+        try {
+            for (int64_t c; !err.set() && (c = next.fetch_add(1)) < nchunks;) fn(c);
+        } catch (...) {
+            err.capture();
+        }
+    };
     std::vector<std::thread> th;
     th.reserve(nt);
-    for (int t = 0; t < nt; ++t)
-        th.emplace_back([&] {
-            for (int64_t c; (c = next.fetch_add(1)) < nchunks;) fn(c);
-        });
+    try {
+        for (int t = 1; t < nt; ++t) th.emplace_back(body);
+    } catch (...) {  // thread creation failed: the ones that started finish the section with the caller
+        err.capture();
+    }
+    body();
     for (auto &t : th) t.join();
+    err.rethrow();
 }
 
 // the same, fn(chunk, worker) with worker in [0, host_threads()): for per-worker scratch
@@ -46,13 +98,24 @@ void parallel_chunks_tid(int64_t nchunks, F &&fn) {
         return;
     }
     std::atomic<int64_t> next{0};
+    FirstError err;
+    auto body = [&](int t) {
+        try {
+            for (int64_t c; !err.set() && (c = next.fetch_add(1)) < nchunks;) fn(c, t);
+        } catch (...) {
+            err.capture();
+        }
+    };
     std::vector<std::thread> th;
     th.reserve(nt);
-    for (int t = 0; t < nt; ++t)
-        th.emplace_back([&, t] {
-            for (int64_t c; (c = next.fetch_add(1)) < nchunks;) fn(c, t);
-        });
+    try {
+        for (int t = 1; t < nt; ++t) th.emplace_back(body, t);
+    } catch (...) {
+        err.capture();
+    }
+    body(0);
     for (auto &t : th) t.join();
+    err.rethrow();
 }
 
 // A pool for callers that issue MANY small parallel sections (the clustering runs one per batch of 4096 communities:
@@ -80,19 +143,29 @@ class WorkerPool {
             for (int64_t c = 0; c < nchunks; ++c) fn(c, 0);
             return;
         }
+        FirstError err;
         {
             std::lock_guard<std::mutex> lk(m_);
             fn_ = &fn;
+            err_ = &err;
             nchunks_ = nchunks;
             next_.store(0);
             busy_ = n_ - 1;
             ++gen_;
         }
         cv_.notify_all();
-        for (int64_t c; (c = next_.fetch_add(1)) < nchunks;) fn(c, 0);
-        std::unique_lock<std::mutex> lk(m_);
-        done_cv_.wait(lk, [this] { return busy_ == 0; });
-        fn_ = nullptr;
+        try {
+            for (int64_t c; !err.set() && (c = next_.fetch_add(1)) < nchunks;) fn(c, 0);
+        } catch (...) {
+            err.capture();
+        }
+        {  // the workers still hold &fn and &err: wait for every one of them, whatever happened above
+            std::unique_lock<std::mutex> lk(m_);
+            done_cv_.wait(lk, [this] { return busy_ == 0; });
+            fn_ = nullptr;
+            err_ = nullptr;
+        }
+        err.rethrow();
     }
 
    private:
@@ -100,6 +173,7 @@ class WorkerPool {
         uint64_t seen = 0;
         for (;;) {
             const std::function<void(int64_t, int)> *fn;
+            FirstError *err;
             int64_t n;
             {
                 std::unique_lock<std::mutex> lk(m_);
@@ -107,9 +181,14 @@ class WorkerPool {
                 seen = gen_;
                 if (stop_) return;
                 fn = fn_;
+                err = err_;
                 n = nchunks_;
             }
-            for (int64_t c; (c = next_.fetch_add(1)) < n;) (*fn)(c, tid);
+            try {
+                for (int64_t c; !err->set() && (c = next_.fetch_add(1)) < n;) (*fn)(c, tid);
+            } catch (...) {
+                err->capture();
+            }
             {
                 std::lock_guard<std::mutex> lk(m_);
                 if (--busy_ == 0) done_cv_.notify_one();
@@ -121,6 +200,7 @@ class WorkerPool {
     std::mutex m_;
     std::condition_variable cv_, done_cv_;
     const std::function<void(int64_t, int)> *fn_ = nullptr;
+    FirstError *err_ = nullptr;
     int64_t nchunks_ = 0;
     std::atomic<int64_t> next_{0};
     int busy_ = 0;

@@ -70,9 +70,14 @@ int kernel_attributes(int lanes_per_nz, bool off32, bool vec4, hipFuncAttributes
 int launch_gather_rows(float *dst, const float *src, const int32_t *idx, int64_t n, int k, hipStream_t s);
 int launch_tiles(const TileView &tv, bool off32, const float *dB, float *dC, int k, int ldb, int ldc, hipStream_t s);
 
+// FLEX_PLAN_TIMING in the environment: phase times of the planner and the clustering on stderr.  The only environment
+// variable the library reads; every tuning knob is a field of flex_plan_tuning (include/flex_spmm.h).
+bool plan_timing_enabled();
+
 // host-side helpers shared by the ABI files
 int order_rcm_host(int64_t n, const uint32_t *rowPtr, const uint32_t *col, std::vector<uint32_t> &rank);
-int order_cluster_host(int64_t n, const uint32_t *rowPtr, const uint32_t *col, std::vector<uint32_t> &rank);
+int order_cluster_host(int64_t n, const uint32_t *rowPtr, const uint32_t *col, std::vector<uint32_t> &rank,
+                       const flex_cluster_tuning *tuning = nullptr);
 int order_gorder_host(int64_t n, const uint32_t *rowPtr, const uint32_t *col, uint32_t window,
                       std::vector<uint32_t> &rank);
 int validate_csr(const flex_csr *A);

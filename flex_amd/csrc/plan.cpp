@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstddef>
 #include <cstdlib>
 #include <new>
 
@@ -45,12 +46,9 @@ int validate_csr(const flex_csr *A) {
     return bad.load() ? FLEX_ERR_INVALID : FLEX_OK;
 }
 
-long env_long(const char *name, long dflt) {
-    const char *s = std::getenv(name);
-    if (!s || !*s) return dflt;
-    char *e = nullptr;
-    long v = std::strtol(s, &e, 10);
-    return (e && *e == 0 && v > 0) ? v : dflt;
+bool plan_timing_enabled() {
+    static const bool on = std::getenv("FLEX_PLAN_TIMING") != nullptr;
+    return on;
 }
 
 void free_plan_device(flex_plan *p) {
@@ -82,7 +80,7 @@ namespace {
 // not on the value), and the fastest plan is kept.  Costs two extra plans and 2 * 4*(n*ldb + m*ldc) bytes for the
 // duration of the call.
 int autotune(flex_plan **pp, const flex_csr *A, int32_t r0, int32_t r1, const int32_t *col_map, const int32_t *dst_map,
-             unsigned flags, std::vector<uint32_t> &sched_cache) {
+             unsigned flags, const flex_plan_tuning &tuning, std::vector<uint32_t> &sched_cache) {
     flex_plan *best = *pp;
     if (best->m == 0 || best->k % 4 != 0 || best->ldb % 4 != 0 || best->ldc % 4 != 0) return FLEX_OK;
     int g_max = 8;
@@ -120,7 +118,7 @@ int autotune(flex_plan **pp, const flex_csr *A, int32_t r0, int32_t r1, const in
         q->m = best->m; q->n = best->n; q->k = best->k; q->device = best->device;
         q->ldb = best->ldb; q->ldc = best->ldc; q->nnz = best->nnz;
         double us = 0.0;
-        int rq = build_plan(q, A, r0, r1, col_map, dst_map, flags, &sched_cache, g);
+        int rq = build_plan(q, A, r0, r1, col_map, dst_map, flags, tuning, &sched_cache, g);
         if (rq == FLEX_OK && hipDeviceSynchronize() != hipSuccess) rq = FLEX_ERR_HIP;
         if (rq == FLEX_OK) time_plan(q, &us);
         if (rq == FLEX_OK && !rc && us < best_us) {
@@ -142,11 +140,24 @@ int autotune(flex_plan **pp, const flex_csr *A, int32_t r0, int32_t r1, const in
 
 extern "C" {
 
+// every knob is "0 = rule" or a small positive number; anything negative or absurd is a caller bug, not a request
+static bool tuning_ok(const flex_plan_tuning &t) {
+    const int32_t *f = reinterpret_cast<const int32_t *>(&t);
+    for (size_t i = 0; i < sizeof(t) / sizeof(int32_t); ++i)
+        if (f[i] < 0 || f[i] > (1 << 28)) return false;
+    for (int32_t r : t.reserved)
+        if (r != 0) return false;
+    return true;
+}
+
 static int create_common(flex_plan **out, const flex_csr *hostA, int64_t row_begin, int64_t row_end,
                          const int32_t *col_map, const int32_t *dst_map, int k, int device, unsigned flags,
-                         int ldb = 0, int ldc = 0) {
+                         int ldb = 0, int ldc = 0, const flex_plan_tuning *tuning_in = nullptr) {
     if (!out) return FLEX_ERR_INVALID;
     *out = nullptr;
+    const flex_plan_tuning tuning = tuning_in ? *tuning_in : flex_plan_tuning{};
+    if (!tuning_ok(tuning)) return FLEX_ERR_INVALID;
+    const HostThreadsScope threads_for_this_call(tuning.host_threads);
     if (k <= 0 || device < 0) return FLEX_ERR_INVALID;
     if (ldb == 0) ldb = k;
     if (ldc == 0) ldc = k;
@@ -179,9 +190,9 @@ static int create_common(flex_plan **out, const flex_csr *hostA, int64_t row_beg
     std::vector<uint32_t> sched_cache;
     const bool tune = (flags & FLEX_PLAN_AUTOTUNE) != 0;
     try {
-        rc = build_plan(p, hostA, static_cast<int32_t>(row_begin), static_cast<int32_t>(row_end), col_map, dst_map, flags,
+        rc = build_plan(p, hostA, static_cast<int32_t>(row_begin), static_cast<int32_t>(row_end), col_map, dst_map, flags, tuning,
                         tune ? &sched_cache : nullptr);
-        if (rc == FLEX_OK && tune) rc = autotune(&p, hostA, static_cast<int32_t>(row_begin), static_cast<int32_t>(row_end), col_map, dst_map, flags, sched_cache);
+        if (rc == FLEX_OK && tune) rc = autotune(&p, hostA, static_cast<int32_t>(row_begin), static_cast<int32_t>(row_end), col_map, dst_map, flags, tuning, sched_cache);
     } catch (const std::bad_alloc &) {  // nothing crosses the C ABI as an exception
         rc = FLEX_ERR_NOMEM;
     } catch (...) {
@@ -224,12 +235,17 @@ int flex_plan_create_rows(flex_plan **out, const flex_csr *hostA, int64_t row_be
 }
 
 int flex_plan_create_ex(flex_plan **out, const flex_plan_desc *d) {
-    if (!d || !d->A || d->struct_size != sizeof(flex_plan_desc)) return FLEX_ERR_INVALID;
+    constexpr size_t kSizeAbi2 = offsetof(flex_plan_desc, tuning);  // a caller built against ABI 2: no tuning member
+    if (!d || !d->A || (d->struct_size != sizeof(flex_plan_desc) && d->struct_size != kSizeAbi2)) return FLEX_ERR_INVALID;
+    const flex_plan_tuning *tuning = d->struct_size == sizeof(flex_plan_desc) ? d->tuning : nullptr;
     const bool all_rows = (d->flags & FLEX_PLAN_ROW_RANGE) == 0;  // with the flag, (0,0) is an EMPTY shard, not "everything"
+    // without the flag the range members must be zero: a shard range passed by a caller that forgot the flag (or was built before
+    // the flag existed) would otherwise get a plan over ALL rows and flex_spmm would write past the shard's C buffer
+    if (all_rows && (d->row_begin != 0 || d->row_end != 0)) return FLEX_ERR_INVALID;
     const int64_t r0 = d->row_begin, r1 = all_rows ? d->A->m : d->row_end;
     if (d->row_map && (!all_rows || d->A->m != d->A->n)) return FLEX_ERR_INVALID;  // a row map renames ALL rows of a graph
     if (!all_rows && (d->flags & FLEX_ORDER_MASK) != FLEX_ORDER_NATURAL) return FLEX_ERR_INVALID;  // reorder first, then shard
-    return create_common(out, d->A, all_rows ? 0 : r0, r1, d->col_map, d->row_map, d->k, d->device, d->flags & ~FLEX_PLAN_ROW_RANGE, d->ldb, d->ldc);
+    return create_common(out, d->A, all_rows ? 0 : r0, r1, d->col_map, d->row_map, d->k, d->device, d->flags & ~FLEX_PLAN_ROW_RANGE, d->ldb, d->ldc, tuning);
 }
 
 int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream) {
@@ -283,6 +299,17 @@ int flex_plan_get_info(const flex_plan *p, flex_plan_info *o) {
     o->n_records = static_cast<int64_t>(p->n_records);
     o->panel_rows = p->two_d ? static_cast<int32_t>(p->panel_rows) : 0;
     return FLEX_OK;
+}
+
+int flex_plan_get_tuning(const flex_plan *p, flex_plan_tuning *o) {
+    if (!p || !o) return FLEX_ERR_INVALID;
+    *o = p->tuning;
+    return FLEX_OK;
+}
+
+int flex_set_host_threads(int n) {
+    if (n < 0) n = 0;
+    return host_threads_cap().exchange(n);
 }
 
 int flex_plan_get_stats(const flex_plan *p, flex_plan_stats *o) {

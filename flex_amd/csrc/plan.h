@@ -50,12 +50,11 @@ struct flex_plan {
     double plan_ms = 0;
     bool has_stats = false;
     flex_plan_stats stats{};
+    flex_plan_tuning tuning{};  // the knobs this plan was built with, rules resolved (flex_plan_get_tuning)
 };
 
 namespace flex {
 
-// A positive integer from the environment, or `dflt` (plan-time tuning knobs; nothing in the product sets them).
-long env_long(const char *name, long dflt);
 
 // std::vector<T>(n) zero-fills: for the record stream (8 B per nonzero) that is a single-threaded pass over gigabytes that
 // the parallel fill overwrites straight away.  With this allocator resize() leaves trivial elements uninitialised, and the
@@ -106,7 +105,7 @@ inline bool operands_vec4(const flex_plan *p, const float *dB, const float *dC) 
 // i.e. slice-local).  sched_cache (or NULL): holds the row schedule once it has been computed, so that several
 // candidate plans of one matrix (autotune) order it only once.  force_G (or 0): lanes per record instead of the degree rule.
 int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const int32_t *col_map, const int32_t *dst_map,
-               unsigned flags, std::vector<uint32_t> *sched_cache = nullptr, int force_G = 0);
+               unsigned flags, const flex_plan_tuning &tuning, std::vector<uint32_t> *sched_cache = nullptr, int force_G = 0);
 
 // ---- block-density detector (dense_tiles.cpp)
 struct DenseTiles {

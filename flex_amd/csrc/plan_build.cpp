@@ -46,10 +46,10 @@ constexpr uint32_t kMaxTasksPerWave = 63;  // the kernel hands descriptors out b
 class PlanBuilder {
    public:
     PlanBuilder(flex_plan *plan, const flex_csr *csr, int32_t row_begin, int32_t row_end, const int32_t *col_map_, const int32_t *dst_map_,
-                unsigned flags_, std::vector<uint32_t> *sched_cache_, int force_G_)
+                unsigned flags_, const flex_plan_tuning &tuning, std::vector<uint32_t> *sched_cache_, int force_G_)
         : p(plan), A(csr), r0(row_begin), r1(row_end), m(row_end - row_begin), k(plan->k), col_map(col_map_), dst_map(dst_map_),
-          flags(flags_), order(flags_ & FLEX_ORDER_MASK), force_G(force_G_), sched(sched_cache_ ? *sched_cache_ : sched_local),
-          have_cache(sched_cache_ != nullptr), timing(std::getenv("FLEX_PLAN_TIMING") != nullptr), t_last(std::chrono::steady_clock::now()) {}
+          flags(flags_), order(flags_ & FLEX_ORDER_MASK), force_G(force_G_), tn(tuning), sched(sched_cache_ ? *sched_cache_ : sched_local),
+          have_cache(sched_cache_ != nullptr), timing(plan_timing_enabled()), t_last(std::chrono::steady_clock::now()) {}
 
     int run() {
         if (order > FLEX_ORDER_GORDER) return FLEX_ERR_INVALID;
@@ -89,10 +89,11 @@ class PlanBuilder {
     const int32_t *const dst_map;  // C row written by row r (NULL = r - r0)
     const unsigned flags, order;
     const int force_G;
+    const flex_plan_tuning &tn;  // the caller's knobs: 0 = the rule of the stage that reads it; p->tuning receives what was used
     std::vector<uint32_t> sched_local;
     std::vector<uint32_t> &sched;  // sched[i] = row of A processed i-th
     const bool have_cache;
-    const bool timing;  // FLEX_PLAN_TIMING: phase times on stderr
+    const bool timing;  // FLEX_PLAN_TIMING (the one environment variable left: it changes nothing but stderr): phase times
     std::chrono::steady_clock::time_point t_last;
 
     // ---- stage results
@@ -133,6 +134,8 @@ class PlanBuilder {
         std::fprintf(stderr, "plan: %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
         t_last = now;
     }
+    // a knob: the caller's value if positive, else the rule's
+    static long pick(int32_t given, long rule) { return given > 0 ? given : rule; }
     uint32_t dst_of(uint32_t r) const { return dst_map ? static_cast<uint32_t>(dst_map[r]) : r - static_cast<uint32_t>(r0); }
     int64_t slice_nnz() const { return static_cast<int64_t>(A->rowPtr[r1]) - A->rowPtr[r0]; }
 
@@ -149,8 +152,8 @@ class PlanBuilder {
         while (4 * G < k && G < 64) G <<= 1;
         if (force_G) {
             G = std::min(G, force_G);
-        } else if (const long g_env = env_long("FLEX_LANES", 0); g_env == 8 || g_env == 16 || g_env == 32 || g_env == 64) {
-            G = std::min<int>(G, static_cast<int>(g_env));  // tuning experiments
+        } else if (const int g_t = tn.lanes_per_nz; g_t == 8 || g_t == 16 || g_t == 32 || g_t == 64) {
+            G = std::min<int>(G, g_t);  // tuning experiments
         } else {
             G = std::min(G, 32);  // k = 256 as two 128-column tiles beats one 256-column tile on every shape measured
             if (avg_deg >= 24.0) G = std::min(G, 16);
@@ -167,7 +170,7 @@ class PlanBuilder {
         } else if (sched.assign(static_cast<size_t>(m), 0u); order != FLEX_ORDER_NATURAL) {
             std::vector<uint32_t> rank;
             const int rc = order == FLEX_ORDER_RCM       ? order_rcm_host(m, A->rowPtr, A->col, rank)
-                           : order == FLEX_ORDER_CLUSTER ? order_cluster_host(m, A->rowPtr, A->col, rank)
+                           : order == FLEX_ORDER_CLUSTER ? order_cluster_host(m, A->rowPtr, A->col, rank, &tn.cluster)
                                                          : order_gorder_host(m, A->rowPtr, A->col, 3, rank);
             if (rc) {
                 sched.clear();
@@ -186,7 +189,7 @@ class PlanBuilder {
         return FLEX_OK;
     }
 
-    // Dense tiles -> MFMA kernel (FLEX_MFMA: 1 = route tiles of fill >= FLEX_MFMA_FILL %, 2 = never; default:
+    // Dense tiles -> MFMA kernel (tuning.mfma: 1 = route tiles of fill >= mfma_fill_pct %, 2 = never; default:
     // route when a sampled look at every 64th row tile finds at least 10 % of the nonzeros in such tiles -- most
     // graphs have none and then pay 1/64 of one pass).  With FLEX_PLAN_STATS the detector looks at every tile, so
     // that its report (share of nonzeros in tiles of fill >= 0.10 / 0.25 / 0.50) is exact.
@@ -195,8 +198,10 @@ class PlanBuilder {
     // fill 0.3 160 -> 217 (slower: a tile costs the same whatever its fill, and its 32 C rows are read and written
     // once more), DESIGN.md 3.5.
     int route_dense_tiles() {
-        const long mode_mfma = env_long("FLEX_MFMA", 0);
-        const uint32_t fill_pct = static_cast<uint32_t>(std::clamp<long>(env_long("FLEX_MFMA_FILL", 60), 1, 100));
+        const long mode_mfma = tn.mfma;
+        const uint32_t fill_pct = static_cast<uint32_t>(std::clamp<long>(pick(tn.mfma_fill_pct, 60), 1, 100));
+        p->tuning.mfma = static_cast<int32_t>(mode_mfma);
+        p->tuning.mfma_fill_pct = static_cast<int32_t>(fill_pct);
         const uint32_t thr = (1024u * fill_pct + 99u) / 100u;
         const bool report = (flags & FLEX_PLAN_STATS) != 0;
         const int64_t nnz_in = slice_nnz();
@@ -257,19 +262,19 @@ class PlanBuilder {
         // small inputs: keep at least ~2048 chunks (two waves per SIMD) before growing them (wiki-Vote shape, k=32:
         // 5.5 us at 128-160 records per chunk, 6.3 at 200)
         auto_budget = std::min(auto_budget, std::max<long>(lo_budget, static_cast<long>(A->rowPtr[r1] - A->rowPtr[r0]) / 2048));
-        wave_nnz = static_cast<uint32_t>(env_long("FLEX_WAVE_NNZ", auto_budget));
-        row_cost = static_cast<uint32_t>(env_long("FLEX_ROW_COST", 16));
+        wave_nnz = static_cast<uint32_t>(pick(tn.chunk_records, auto_budget));
+        row_cost = static_cast<uint32_t>(pick(tn.row_cost, 16));
         // Contiguous XCD slices (workgroup ids remapped) keep a community's rows on ONE private L2; they pay when the
         // eighths of the schedule run at different speeds, because a slice cannot borrow an idle XCD.  Community and
         // natural order: remap on (reddit k=128 cluster 676 vs 811 us without, flickr 38 vs 49, yelp 523 vs 688; natural
         // order the same either way).  RCM / Gorder (BFS-like orders: the eighths differ in L2 hit rate, so cost-balanced
         // slices end 20-34 % apart): the hardware's round-robin over XCDs is faster -- reddit RCM 1160 -> 1102 us (k=32:
-        // 260 -> 251), yelp RCM 973 -> 911, flickr RCM 63.8 -> 60.9, flickr Gorder 59.1 -> 52.7.  FLEX_XCD_REMAP = 1 / 2 forces.
-        const long remap_env = env_long("FLEX_XCD_REMAP", 0);
+        // 260 -> 251), yelp RCM 973 -> 911, flickr RCM 63.8 -> 60.9, flickr Gorder 59.1 -> 52.7.  tuning.xcd_slices = 1 / 2 forces.
+        const long remap_env = tn.xcd_slices;
         // A reordered loader planned as given says so itself: FLEX_PLAN_XCD_INTERLEAVE.
         const bool interleave = order == FLEX_ORDER_RCM || order == FLEX_ORDER_GORDER || (flags & FLEX_PLAN_XCD_INTERLEAVE) != 0;
         p->xcd_remap = remap_env == 1 || (remap_env != 2 && !interleave);
-        p->lds_extra = static_cast<unsigned>(env_long("FLEX_LDS_EXTRA", 1)) & ~15u;  // default 0 (1 -> 0)
+        p->lds_extra = static_cast<unsigned>(std::max(0, tn.lds_extra)) & ~15u;
         // The record stream is read once per column tile.  Non-temporal loads keep it from displacing B rows in the L2s and
         // the Infinity Cache, but they also come back slower and sit on the header -> records -> gathers chain of every chunk.
         // Measured on MI355X (same box each):
@@ -277,20 +282,20 @@ class PlanBuilder {
         //   one tile, stream of 0.1-0.2 GB:           reddit k=32 178 -> 196 us, yelp k=32 130 -> 148 us   (worse)
         //   one tile, stream of 2.1 GB (8x the Infinity Cache): amazon k=32 2.43 -> 2.29 ms
         //   small streams:                            flickr k=128 37.9 -> 40.4 us                          (worse)
-        // hence: on for multi-tile launches from 32 MB, for single-tile launches only from 1 GiB.  FLEX_REC_NT = 1 / 2 forces.
-        const long nt_env = env_long("FLEX_REC_NT", 0);
+        // hence: on for multi-tile launches from 32 MB, for single-tile launches only from 1 GiB.  tuning.rec_nt = 1 / 2 forces.
+        const long nt_env = tn.rec_nt;
         const int ktiles = (k + 4 * G - 1) / (4 * G);
         const uint64_t stream_bytes = static_cast<uint64_t>(A->rowPtr[r1] - A->rowPtr[r0]) * 8u;
         p->rec_nt = nt_env == 1 || (nt_env != 2 && stream_bytes >= (ktiles >= 2 ? (32ull << 20) : (1ull << 30)));
-        p->unroll = static_cast<int>(env_long("FLEX_U", 0));
+        p->unroll = tn.unroll == 8 ? 8 : 0;
         // Rows longer than one budget are cut into pieces of one budget, each a chunk of its own that
         // writes a k-wide partial sum: one wave keeps only U gathers in flight, so a long row is much
         // faster as several concurrent pieces (flickr, MI355X: 88 us with no splitting, 43 us with
         // rows > 192 records split, 40 us with rows > 96 split; reddit is flat from 256 to 512;
         // DESIGN.md 3.3).  Pieces stay in schedule order: moving them to the
         // front of the XCD slices helped flickr by 3 % and cost reddit 12 % (half its chunks are pieces).
-        long_row = static_cast<uint32_t>(env_long("FLEX_LONG_ROW", wave_nnz));
-        piece_len = std::max<uint32_t>(S, static_cast<uint32_t>(env_long("FLEX_PIECE", wave_nnz)) / S * S);
+        long_row = static_cast<uint32_t>(pick(tn.long_row, wave_nnz));
+        piece_len = std::max<uint32_t>(S, static_cast<uint32_t>(pick(tn.piece_records, wave_nnz)) / S * S);
 
         // Column panels (the 2-D schedule; ≙ the column spans of csr2_DiagTiling's rounds 2-3, mat.cu:680-942, and
         // csr2seg_Cmajor, mat.cu:1192-1269, re-thought for eight private 4 MiB L2s).  An XCD walks ONE contiguous slice of
@@ -301,13 +306,29 @@ class PlanBuilder {
         // construction; the price is that a row with records in several phases is summed from several pieces (a k-wide
         // partial sum written and read once per piece).  Only runs of >= `seg_min` records of a row in one panel become a
         // piece; the rest of the row (its scattered columns, which miss either way) is ONE more piece in a last phase.
-        // The rule is "off": decided by measurement; FLEX_2D = 1 forces it on (tests, tuning), any size.
-        two_d = env_long("FLEX_2D", 0) == 1 && m > 0;
+        // The rule is "off": decided by measurement; tuning.two_d = 1 forces it on (tests, tuning), any size.
+        two_d = tn.two_d == 1 && m > 0;
         const uint64_t tile_bytes = 16ull * static_cast<uint64_t>(G);  // one B row of one column tile
-        const uint64_t panel_bytes = static_cast<uint64_t>(env_long("FLEX_PANEL_KB", 2048)) << 10;
+        const uint64_t panel_bytes = static_cast<uint64_t>(pick(tn.panel_kb, 2048)) << 10;
         pshift = 0;
         while ((2ull << pshift) * tile_bytes <= panel_bytes) ++pshift;  // P = 2^pshift rows of B per panel
-        seg_min = static_cast<uint32_t>(env_long("FLEX_SEG_MIN", 4));
+        seg_min = static_cast<uint32_t>(pick(tn.seg_min, 4));
+        // what this plan was built with (flex_plan_get_tuning)
+        flex_plan_tuning &u = p->tuning;
+        u.lanes_per_nz = G;
+        u.chunk_records = static_cast<int32_t>(wave_nnz);
+        u.long_row = static_cast<int32_t>(long_row);
+        u.piece_records = static_cast<int32_t>(piece_len);
+        u.row_cost = static_cast<int32_t>(row_cost);
+        u.xcd_slices = p->xcd_remap ? 1 : 2;
+        u.rec_nt = p->rec_nt ? 1 : 2;
+        u.unroll = p->unroll;
+        u.two_d = two_d ? 1 : 0;
+        u.panel_kb = static_cast<int32_t>(panel_bytes >> 10);
+        u.seg_min = static_cast<int32_t>(seg_min);
+        u.lds_extra = static_cast<int32_t>(p->lds_extra);
+        u.host_threads = host_threads();
+        u.cluster = tn.cluster;
     }
 
     // A run of `len` records as pieces: one, or (longer than a budget) several of about one budget.  The last piece to
@@ -587,7 +608,8 @@ class PlanBuilder {
             return make_uint4(w_task[c], w_task[c + 1] - w_task[c], t_beg[w_task[c]], t_beg[w_task[c + 1]]);
         };
         std::vector<uint4> chunk;
-        if (two_d || (p->xcd_remap && n_real >= 8u * kXcds * kWavesPerBlock && env_long("FLEX_XCD_BALANCE", 1) != 2)) {
+        p->tuning.xcd_balance = tn.xcd_balance == 2 ? 2 : 1;
+        if (two_d || (p->xcd_remap && n_real >= 8u * kXcds * kWavesPerBlock && tn.xcd_balance != 2)) {
             uint32_t cut[kXcds + 1];
             cut[0] = 0;
             cut[kXcds] = n_real;
@@ -596,8 +618,10 @@ class PlanBuilder {
             } else {
                 // cost of a chunk in units of one 512-byte gather (a record at k = 128): measured per-XCD times
                 // on the flickr shape fit  t = a * records + ~20 a * chunks  with rows nearly free
-                const uint64_t chunk_cost = static_cast<uint64_t>(env_long("FLEX_CHUNK_COST", 16)) * 32u;
-                const uint64_t task_cost = static_cast<uint64_t>(env_long("FLEX_TASK_COST", 2)) * 32u;
+                const uint64_t chunk_cost = static_cast<uint64_t>(pick(tn.chunk_cost, 16)) * 32u;
+                const uint64_t task_cost = static_cast<uint64_t>(pick(tn.task_cost, 2)) * 32u;
+                p->tuning.chunk_cost = static_cast<int32_t>(chunk_cost / 32u);
+                p->tuning.task_cost = static_cast<int32_t>(task_cost / 32u);
                 std::vector<uint64_t> cum(n_real + 1, 0);
                 for (uint32_t c = 0; c < n_real; ++c) {
                     const uint4 h = header(c);
@@ -631,7 +655,13 @@ class PlanBuilder {
         std::vector<uint32_t> zeros(std::max<size_t>(1, split.size() * ktiles), 0u);
         if ((rc = upload(&p->d_split_cnt, zeros, &p->device_bytes))) return rc;
         const size_t pbytes = std::max<size_t>(1, static_cast<size_t>(n_partials) * k) * sizeof(float);
-        p->fused_fixup = env_long("FLEX_FUSED_FIXUP", 1) == 1;
+        // Split rows are summed by spmm_fixup_kernel after the main launch: stream order is all that needs, and it measured
+        // FASTER than the in-launch form on the large shapes (MI355X, profiles/r03_fixup_in_launch_vs_two_launch.txt: reddit k=128
+        // 638 vs 642 us, amazon 8.22 vs 8.27 ms; flickr 38.5 vs 36.7 us and reddit k=32 151 vs 150 the other way: one kernel
+        // boundary).  tuning.split_rows = 1 asks for the in-launch form (relaxed agent atomics + sc1 hand-off: measured on
+        // gfx950, not an architectural guarantee; spmm_kernels.hip).
+        p->fused_fixup = tn.split_rows == 1;
+        p->tuning.split_rows = p->fused_fixup ? 1 : 2;
         FLEX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_partial), pbytes));
         p->device_bytes += static_cast<int64_t>(pbytes);
         return FLEX_OK;
@@ -641,8 +671,8 @@ class PlanBuilder {
 }  // namespace
 
 int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const int32_t *col_map, const int32_t *dst_map, unsigned flags,
-               std::vector<uint32_t> *sched_cache, int force_G) try {
-    return PlanBuilder(p, A, r0, r1, col_map, dst_map, flags, sched_cache, force_G).run();
+               const flex_plan_tuning &tuning, std::vector<uint32_t> *sched_cache, int force_G) try {
+    return PlanBuilder(p, A, r0, r1, col_map, dst_map, flags, tuning, sched_cache, force_G).run();
 } catch (const std::bad_alloc &) {  // any host allocation of any stage
     return FLEX_ERR_NOMEM;
 }

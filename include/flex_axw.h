@@ -22,6 +22,7 @@ typedef struct flex_axw flex_axw;
 #define FLEX_AXW_A_XW 1 /* run1: B = X*W (n x c), Out = A*B : cheapest when c < dim */
 #define FLEX_AXW_AX_W 2 /* run2: B = A*X (n x dim), Out = B*W */
 #define FLEX_AXW_AUTO 0 /* the order with fewer SpMM columns (SpMM dominates both) */
+#define FLEX_AXW_USE_BLAS 0x10000u /* flex_axw_create flag: rocBLAS SGEMM for the dense half instead of the hand-written MFMA kernel (tools/probe_axw.py) */
 
 /* Leading dimension of Out and of the X*W intermediate: c rounded up to a multiple of 32 floats, so
  * that every row is a whole number of 128-byte cache lines (a row that starts mid-line costs each

@@ -24,7 +24,9 @@
 extern "C" {
 #endif
 
-#define FLEX_ABI_VERSION 2 /* 2: flex_plan_info / flex_plan_stats grew (2-D, MFMA tiles, records, detector report); flex_plan_desc flag FLEX_PLAN_ROW_RANGE; flex_order_rabbit, flex_plan_measure_imbalance */
+#define FLEX_ABI_VERSION 3 /* 3: plan-time knobs leave the environment for the struct flex_plan_tuning, flex_plan_desc.tuning, flex_plan_get_tuning,
+                              flex_order_cluster_ex, flex_set_host_threads; split rows are summed by a second launch by default.
+                              2: flex_plan_info / flex_plan_stats grew; FLEX_PLAN_ROW_RANGE; flex_order_rabbit, flex_plan_measure_imbalance */
 
 typedef enum flex_status {
     FLEX_OK = 0,
@@ -111,6 +113,41 @@ int flex_plan_create_rows(flex_plan **out, const flex_csr *hostA, int64_t row_be
  *   col_map            column c of A reads B row col_map[c] (NULL = c)
  *   row_map            row r of A writes C row row_map[r] (NULL = r - row_begin); all rows only, A square
  *   ldb/ldc            row strides of B and C in floats (0 = k) */
+/* Plan-time tuning knobs (ABI 3; rounds 1-2 read them from the environment, which is process-global and racy).  Every
+ * field: 0 = the planner's measured rule.  Nothing in the product sets them; they exist for the tests, the
+ * soak and tools/.  flex_plan_get_tuning returns the values a plan was actually built with. */
+typedef struct flex_cluster_tuning { /* flex_order_cluster_ex / FLEX_ORDER_CLUSTER plans */
+    int32_t batch;     /* proposals per batch of the agglomeration (4096) */
+    int32_t no_refine; /* 1: skip the second stage (vertex moves between stretches of the order) */
+    int32_t stretch;   /* positions per stretch (1024), >= 16 */
+    int32_t sweeps;    /* sweep limit (8) */
+    int32_t stride;    /* largest sampling stride of a long row (4) */
+} flex_cluster_tuning;
+typedef struct flex_plan_tuning {
+    int32_t lanes_per_nz;    /* G = 8 / 16 / 32 / 64 lanes per record (column tile of 4G columns), capped by k */
+    int32_t chunk_records;   /* chunk budget: records per wave */
+    int32_t long_row;        /* rows longer than this are cut into pieces (chunk_records) */
+    int32_t piece_records;   /* ... of about this many records (chunk_records) */
+    int32_t row_cost;        /* records a row boundary counts for when chunks are cut (16) */
+    int32_t xcd_slices;      /* 1: every XCD walks one contiguous slice of the schedule; 2: round-robin (rule: 1 except RCM / Gorder) */
+    int32_t xcd_balance;     /* 2: slices cut by chunk count instead of by cost */
+    int32_t chunk_cost, task_cost; /* cost model of the slice balancing (16, 2) */
+    int32_t split_rows;      /* how the pieces of a split row are summed: 2 = by spmm_fixup_kernel after the launch (the default: it
+                                needs nothing beyond stream order); 1 = inside the launch by the piece that arrives last (relaxed
+                                agent atomics + sc1 stores and loads: measured on gfx950, not an architectural guarantee) */
+    int32_t rec_nt;          /* record stream read with non-temporal loads: 1 on, 2 off */
+    int32_t unroll;          /* 8: eight gathers in flight per wave on the narrow tiles too */
+    int32_t two_d;           /* 1: rows are also cut by column panel (the 2-D schedule) */
+    int32_t panel_kb;        /* ... panel = this many KiB of one column tile of B (2048) */
+    int32_t seg_min;         /* ... runs shorter than this stay in the row's last piece (4) */
+    int32_t mfma;            /* dense 32x32 tiles to the MFMA kernel: 1 always route, 2 never (rule: when a sample finds >= 10 % of nnz) */
+    int32_t mfma_fill_pct;   /* ... tiles of at least this fill (60) */
+    int32_t lds_extra;       /* bytes of idle LDS per workgroup (occupancy throttle; multiple of 16) */
+    int32_t host_threads;    /* host threads of this call (rule: flex_set_host_threads, else the core count, at most 32) */
+    flex_cluster_tuning cluster;
+    int32_t reserved[16];    /* zero */
+} flex_plan_tuning;
+
 typedef struct flex_plan_desc {
     size_t struct_size;
     const flex_csr *A;
@@ -118,8 +155,15 @@ typedef struct flex_plan_desc {
     unsigned flags;
     int64_t row_begin, row_end;
     const int32_t *col_map, *row_map;
+    const flex_plan_tuning *tuning; /* ABI 3; NULL = rules.  A caller built against ABI 2 passes the shorter struct_size */
 } flex_plan_desc;
 int flex_plan_create_ex(flex_plan **out, const flex_plan_desc *desc);
+int flex_plan_get_tuning(const flex_plan *plan, flex_plan_tuning *out);
+
+/* Process-wide cap on the worker threads of the planner, the orderings and the generator (0 = the core count, at most
+ * 32 either way); returns the previous value.  For N ranks on one host: host cores / N.  Thread-safe; results never
+ * depend on the thread count (tests/test_planner_host.py). */
+int flex_set_host_threads(int n);
 
 /* ≙ launch_prep + cudaMemset(C) + kernel<<<>>> (mat.cu:32-41, flex.cu:5057-5059).
  * dB: n x k row-major device fp32; dC: m x k row-major device fp32, fully overwritten
@@ -311,6 +355,7 @@ int flex_order_deg(const flex_csr *A, int descending, uint32_t *rank);
  * + a walk of the merge forest, then a few sweeps of vertex moves between stretches of that order (kept only when they
  * put more edges within 2048 positions).  Deterministic: the same rank for any number of host threads. */
 int flex_order_cluster(const flex_csr *A, uint32_t *rank);
+int flex_order_cluster_ex(const flex_csr *A, const flex_cluster_tuning *tuning /* NULL = rules */, uint32_t *rank);
 
 /* ≙ DataLoaderRcm body (DataLoader.cu:741-779): vo_mp[new]=old + permuted CSR, columns
  * ascending per row. Outputs caller-allocated with the sizes of A. */

@@ -34,3 +34,25 @@ def pubmed():
 def a_mat():
     import oracle
     return oracle.csv_load(os.path.join(GOLDEN, "a_mat.csv"))
+
+
+class _Knobs:
+    """Plan-time knobs (fields of flex_plan_tuning) for every Plan() created while a test runs, also inside helpers:
+    knobs.set(two_d=1, panel_kb=32); knobs.clear("two_d").  Reset when the test ends."""
+
+    def set(self, **kw):
+        from flex_amd import binding
+        binding.DEFAULT_TUNING.update({k: int(v) for k, v in kw.items()})
+
+    def clear(self, *names):
+        from flex_amd import binding
+        for n in names or list(binding.DEFAULT_TUNING):
+            binding.DEFAULT_TUNING.pop(n, None)
+
+
+@pytest.fixture
+def knobs():
+    k = _Knobs()
+    k.clear()
+    yield k
+    k.clear()

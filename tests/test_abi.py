@@ -19,7 +19,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     L = ctypes.CDLL(flex_amd.lib_path())
     for s in declared:
         assert hasattr(L, s), s
-    assert flex_amd.lib().flex_abi_version() == 2
+    assert flex_amd.lib().flex_abi_version() == 3
 
 
 @pytest.mark.parametrize("header,lib", [("flex_spmm.h", "libflex_spmm.so"), ("flex_vendor.h", "libflex_vendor.so"),
@@ -207,7 +207,7 @@ def test_cluster_and_deg_orders_are_permutations_with_locality():
     assert np.all(np.diff(d[np.argsort(deg)]) <= 0)  # order_deg(desc): degrees descend along the new order
 
 
-def test_second_stage_of_the_community_order_moves_vertices_to_their_neighbours(monkeypatch):
+def test_second_stage_of_the_community_order_moves_vertices_to_their_neighbours():
     """The vertex-move stage (cluster.cpp, refine_by_label_moves) on a planted-community graph: still a permutation, the same
     for 1, 3 and 8 host threads, and more of the edges end up within 1024 positions than after the merge forest's walk alone."""
     g = flex_amd.synth_graph(n=60000, nnz=60000 + 2 * 900000, community=1500, p_in=0.6, p_near=0.25, seed=11)
@@ -215,13 +215,14 @@ def test_second_stage_of_the_community_order_moves_vertices_to_their_neighbours(
 
     def near(rank, w=1024):
         return float(np.mean(np.abs(rank[rows].astype(np.int64) - rank[g.col].astype(np.int64)) < w))
-    monkeypatch.setenv("FLEX_CLUSTER_NO_REFINE", "1")
-    walk = flex_amd.order_cluster(g)
-    monkeypatch.delenv("FLEX_CLUSTER_NO_REFINE")
+    walk = flex_amd.order_cluster(g, no_refine=1)
     ranks = []
-    for threads in ("1", "3", "8"):
-        monkeypatch.setenv("FLEX_HOST_THREADS", threads)
-        ranks.append(flex_amd.order_cluster(g))
+    for threads in (1, 3, 8):
+        old = flex_amd.set_host_threads(threads)
+        try:
+            ranks.append(flex_amd.order_cluster(g))
+        finally:
+            assert flex_amd.set_host_threads(old) == threads
     assert np.array_equal(ranks[0], ranks[1]) and np.array_equal(ranks[0], ranks[2])
     assert sorted(ranks[0].tolist()) == list(range(g.n))
     assert near(ranks[0]) > near(walk) + 0.03, (near(ranks[0]), near(walk))
@@ -240,9 +241,7 @@ def test_second_stage_of_the_community_order_moves_vertices_to_their_neighbours(
     rp = np.zeros((1 << scale) + 1, dtype=np.int64)
     np.cumsum(np.bincount(rr, minlength=1 << scale), out=rp[1:])
     rmat = flex_amd.HostCsr(rp.astype(np.uint32), cc.astype(np.uint32), np.ones(len(cc), np.float32), n=1 << scale)
-    monkeypatch.setenv("FLEX_CLUSTER_NO_REFINE", "1")
-    walk_rmat = flex_amd.order_cluster(rmat)
-    monkeypatch.delenv("FLEX_CLUSTER_NO_REFINE")
+    walk_rmat = flex_amd.order_cluster(rmat, no_refine=1)
     rows_rmat = np.repeat(np.arange(rmat.m), np.diff(rp))
     staged = flex_amd.order_cluster(rmat)
 
@@ -252,8 +251,7 @@ def test_second_stage_of_the_community_order_moves_vertices_to_their_neighbours(
     # too small to cut into stretches: the walk's order is kept as it is
     small = flex_amd.synth_graph(n=3000, nnz=3000 + 2 * 20000, community=50, p_in=0.5, p_near=0.2, seed=1)
     r1 = flex_amd.order_cluster(small)
-    monkeypatch.setenv("FLEX_CLUSTER_NO_REFINE", "1")
-    assert np.array_equal(r1, flex_amd.order_cluster(small))
+    assert np.array_equal(r1, flex_amd.order_cluster(small, no_refine=1))
 
 
 def test_dfs_order_equals_oracle_and_is_a_preorder():

@@ -308,17 +308,20 @@ def test_vendor_baseline_matches_oracle():
     assert_matches_oracle(a, B, Cd.cpu().numpy())
 
 
-def test_in_launch_split_row_reduction_is_stable_under_repetition():
-    """Split rows are summed inside the launch by the last piece to arrive (write-through partial sums,
-    agent-scope arrival counter, sc1 re-reads).  A visibility bug would show as a rare wrong row:
-    hammer a plan that is mostly split rows and require every launch to be bit-identical and correct."""
+@pytest.mark.parametrize("split_rows", [1, 2])
+def test_split_row_reduction_is_stable_under_repetition(knobs, split_rows):
+    """split_rows = 1: split rows are summed inside the launch by the last piece to arrive (write-through partial sums,
+    agent-scope arrival counter, sc1 re-reads; opt-in since ABI 3).  A visibility bug would show as a rare wrong row:
+    hammer a plan that is mostly split rows and require every launch to be bit-identical and correct.  split_rows = 2
+    (the default: spmm_fixup_kernel after the launch) goes through the same hammering."""
+    knobs.set(split_rows=split_rows)
     a = random_csr(6000, 6000, 8, seed=91, long_rows={r: 700 + 13 * (r % 97) for r in range(0, 6000, 3)}, empty_frac=0.05)
     k = 128
     Bn = random_B(a.n, k, 92)
     B = dev(Bn)
     p = Plan(a, k)
     info = p.info()
-    assert info["n_split_rows"] >= 1900 and info["n_partials"] > 5000
+    assert info["n_split_rows"] >= 1900 and info["n_partials"] > 5000 and p.tuning()["split_rows"] == split_rows
     ref = p(B).clone()
     torch.cuda.synchronize()
     assert_matches_oracle(a, Bn, ref.cpu().numpy(), nthreads=8)
@@ -370,7 +373,7 @@ def test_bench_json_contract():
 
 
 @pytest.mark.parametrize("dense_block", [False, True])
-def test_b_larger_than_4GiB_uses_64bit_row_addressing(monkeypatch, dense_block):
+def test_b_larger_than_4GiB_uses_64bit_row_addressing(knobs, dense_block):
     """n*k*4 > 2^32: records carry column ids instead of 32-bit byte offsets (OFF32 = false kernels); with a dense block of A
     at the far end of the column range the MFMA tile kernel's 64-bit row addressing is exercised too."""
     m, n, k = 1500, 2_200_000, 512
@@ -387,7 +390,7 @@ def test_b_larger_than_4GiB_uses_64bit_row_addressing(monkeypatch, dense_block):
     col = rng.integers(0, n, size=rp[-1]).astype(np.uint32)
     col[:64] = n - 1 - np.arange(64)  # make sure the top of the address range is touched
     if dense_block:
-        monkeypatch.setenv("FLEX_MFMA", "1")
+        knobs.set(mfma=1)
         for r in range(64, 128):
             col[rp[r]:rp[r + 1]] = np.sort(rng.choice(np.arange(n - 64, n), size=60, replace=False)).astype(np.uint32)
     a = flex_amd.HostCsr(rp.astype(np.uint32), col, rng.uniform(-1, 1, rp[-1]).astype(np.float32), n=n)
@@ -489,19 +492,21 @@ def test_hbm_probe_reports_a_plausible_bandwidth():
 
 
 @pytest.mark.parametrize("lanes,k", [(64, 256), (32, 256), (16, 128), (8, 128), (8, 64)])
-def test_every_column_tile_width_gives_the_same_answer(monkeypatch, lanes, k):
+def test_every_column_tile_width_gives_the_same_answer(knobs, lanes, k):
     """The planner picks the lanes-per-record G (column tile = 4G) from k and the average degree; every
     width it can pick -- including G=64, which the default rule never selects -- must pass resCheck,
-    with split rows reduced in-launch across several k-tiles."""
+    with split rows reduced in-launch across several k-tiles (and by the default two-launch form: same bits)."""
     a = random_csr(2500, 2500, 30, seed=21, long_rows={3: 2400, 9: 700})
     B = random_B(2500, k, 4)
-    monkeypatch.setenv("FLEX_LANES", str(lanes))
+    knobs.set(lanes_per_nz=lanes, split_rows=1)
     p = Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER)
     assert p.info()["lanes_per_nz"] == lanes
     C1 = run_plan(p, B)
     assert_matches_oracle(a, B, C1)
     assert np.array_equal(C1, run_plan(p, B))  # deterministic, counters re-armed
-    monkeypatch.delenv("FLEX_LANES")
+    knobs.clear("split_rows")
+    assert np.array_equal(C1, run_plan(Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER), B))  # pieces are added in piece order either way
+    knobs.clear("lanes_per_nz")
     p2 = Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER)
     assert p2.info()["lanes_per_nz"] == 16  # average degree >= 24: narrow tiles by default
     assert_matches_oracle(a, B, run_plan(p2, B))
@@ -586,7 +591,8 @@ def test_seeded_fuzz_over_shapes_degrees_widths_schedules():
         ldb = k + int(rng.choice([0, 4, 28])) if strided else k
         ldc = k + int(rng.choice([0, 4, 28])) if strided else k
         B = rng.uniform(-1, 1, size=(n, ldb)).astype(np.float32)
-        p = Plan(a, k, order=order | flex_amd.FLEX_PLAN_STATS, ldb=ldb, ldc=ldc) if strided else Plan(a, k, order=order | flex_amd.FLEX_PLAN_STATS)
+        how = {"split_rows": 1 + case % 2}  # both forms of the split-row sum
+        p = Plan(a, k, order=order | flex_amd.FLEX_PLAN_STATS, ldb=ldb, ldc=ldc, tuning=how) if strided else Plan(a, k, order=order | flex_amd.FLEX_PLAN_STATS, tuning=how)
         Cd = torch.full((m, ldc), 3.5, dtype=torch.float32, device="cuda")
         p.spmm(torch.from_numpy(B).cuda().data_ptr(), Cd.data_ptr(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
@@ -603,18 +609,19 @@ def test_seeded_fuzz_over_shapes_degrees_widths_schedules():
 
 
 @pytest.mark.parametrize("k", [32, 64, 128])
-def test_two_launch_form_of_split_rows(monkeypatch, k):
-    """FLEX_FUSED_FIXUP=2: the vector kernel leaves the partial sums of split rows to spmm_fixup_kernel (the form
-    the generic kernel always uses, and the fallback when the workspace exceeds the 4 GiB buffer range)."""
+def test_two_launch_form_of_split_rows(knobs, k):
+    """split_rows = 2 (the default since ABI 3): the vector kernel leaves the partial sums of split rows to spmm_fixup_kernel
+    (the form the generic kernel always uses); split_rows = 1 sums them inside the launch.  Same bits."""
     a = random_csr(2500, 2500, 10, seed=51, long_rows={1: 2400, 8: 1100, 900: 300})
     B = random_B(2500, k, 6)
-    monkeypatch.setenv("FLEX_FUSED_FIXUP", "2")
     p = Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER)
-    assert p.info()["n_split_rows"] >= 3
+    assert p.info()["n_split_rows"] >= 3 and p.tuning()["split_rows"] == 2
     C1 = run_plan(p, B)
     assert_matches_oracle(a, B, C1)
-    monkeypatch.delenv("FLEX_FUSED_FIXUP")
-    C2 = run_plan(Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER), B)
+    knobs.set(split_rows=1)
+    p_in = Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER)
+    assert p_in.tuning()["split_rows"] == 1
+    C2 = run_plan(p_in, B)
     assert np.array_equal(C1, C2)  # both forms add the pieces in piece order: bit-identical
 
 
@@ -716,18 +723,16 @@ def test_general_entry_point_covers_combinations():
 
 @pytest.mark.parametrize("k,lanes", [(32, 0), (64, 0), (128, 0), (128, 8), (128, 32), (256, 0), (100, 0), (36, 0), (7, 0)])
 @pytest.mark.parametrize("order", [FLEX_ORDER_NATURAL, flex_amd.FLEX_ORDER_CLUSTER])
-def test_two_d_column_panel_schedule(monkeypatch, k, lanes, order):
+def test_two_d_column_panel_schedule(knobs, k, lanes, order):
     """FLEX_2D=1: every XCD slice of the rows is walked column panel by column panel; a row with records in several
     panels is summed from several pieces (partial slots + arrival counters, many pieces per chunk).  Tiny panels force
     many phases on a small graph: resCheck against the oracle, the plan self-check, bit-identical repeat launches,
     and the same bits from the two-launch form (spmm_fixup_kernel adds the pieces in the same order)."""
     a = flex_amd.synth_graph(n=6000, nnz=6000 + 2 * 90000, community=200, p_in=0.55, p_near=0.3, seed=5)
     B = random_B(a.n, k, 9)
-    monkeypatch.setenv("FLEX_2D", "1")
-    monkeypatch.setenv("FLEX_PANEL_KB", "32")
-    monkeypatch.setenv("FLEX_SEG_MIN", "2")
+    knobs.set(two_d=1, panel_kb=32, seg_min=2, split_rows=1)
     if lanes:
-        monkeypatch.setenv("FLEX_LANES", str(lanes))
+        knobs.set(lanes_per_nz=lanes)
     p = Plan(a, k, order=order)
     info = p.info()
     assert info["two_d"] == 1 and info["panel_rows"] >= 32 and info["n_split_rows"] > a.m // 2 and info["n_partials"] > a.m
@@ -735,22 +740,22 @@ def test_two_d_column_panel_schedule(monkeypatch, k, lanes, order):
     C1 = run_plan(p, B)
     assert_matches_oracle(a, B, C1)
     assert np.array_equal(C1, run_plan(p, B))  # counters re-armed, same piece order
-    monkeypatch.setenv("FLEX_FUSED_FIXUP", "2")
+    knobs.set(split_rows=2)
     p2 = Plan(a, k, order=order)
     assert np.array_equal(C1, run_plan(p2, B))
-    monkeypatch.delenv("FLEX_FUSED_FIXUP")
+    knobs.clear("split_rows")
     # against the 1-D schedule of the same matrix: same tolerance, not the same bits
-    monkeypatch.setenv("FLEX_2D", "2")
+    knobs.clear("two_d")
     p1 = Plan(a, k, order=order)
     assert p1.info()["two_d"] == 0
     assert oracle.rescheck(run_plan(p1, B), C1, a.rowPtr)[0] == 0
 
 
-def test_two_d_with_hubs_empty_rows_shards_and_strides(monkeypatch):
+def test_two_d_with_hubs_empty_rows_shards_and_strides(knobs):
     """2-D plans of awkward inputs: hub rows (runs longer than a budget inside a panel), empty rows, a rectangular
     matrix, row shards with a column map, padded storage."""
-    monkeypatch.setenv("FLEX_2D", "1")
-    monkeypatch.setenv("FLEX_PANEL_KB", "64")
+    knobs.set(two_d=1)
+    knobs.set(panel_kb=64)
     a = random_csr(5000, 5000, 25, seed=77, long_rows={3: 4500, 2500: 1800, 4999: 700}, empty_frac=0.1)
     for k, ldb, ldc in ((128, None, None), (64, 96, 68)):
         B = random_B(a.n, ldb or k, 3)
@@ -785,13 +790,13 @@ def test_two_d_with_hubs_empty_rows_shards_and_strides(monkeypatch):
     assert oracle.rescheck(gold, got, g.rowPtr)[0] == 0
 
 
-def test_two_d_schedule_on_top_of_the_dense_tile_route(monkeypatch):
+def test_two_d_schedule_on_top_of_the_dense_tile_route(knobs):
     """Both plan features at once, executed: dense diagonal blocks go to the MFMA kernel, the rest is walked panel by panel."""
     a = block_dense_graph(6400, 64, 0.85, 12, seed=11)
     B = random_B(a.n, 128, 2)
-    monkeypatch.setenv("FLEX_2D", "1")
-    monkeypatch.setenv("FLEX_PANEL_KB", "64")
-    monkeypatch.setenv("FLEX_SEG_MIN", "2")
+    knobs.set(two_d=1)
+    knobs.set(panel_kb=64)
+    knobs.set(seg_min=2)
     p = Plan(a, 128)
     info = p.info()
     assert info["two_d"] == 1 and info["n_tiles"] > 300 and info["n_partials"] > 0
@@ -801,12 +806,12 @@ def test_two_d_schedule_on_top_of_the_dense_tile_route(monkeypatch):
     assert np.array_equal(C1, run_plan(p, B))
 
 
-def test_two_d_reduction_is_stable_under_repetition(monkeypatch):
+def test_two_d_reduction_is_stable_under_repetition(knobs):
     """The in-launch combination now runs for pieces scattered over many chunks (several arrivals per chunk, up to S
     rows completed per round): 200 launches under uneven load must give the same bits and the right answer."""
-    monkeypatch.setenv("FLEX_2D", "1")
-    monkeypatch.setenv("FLEX_PANEL_KB", "64")
-    monkeypatch.setenv("FLEX_SEG_MIN", "2")
+    knobs.set(two_d=1, split_rows=1)
+    knobs.set(panel_kb=64)
+    knobs.set(seg_min=2)
     a = flex_amd.synth_graph(n=40000, nnz=40000 + 2 * 1500000, community=512, p_in=0.5, p_near=0.3, seed=8)
     k = 128
     Bn = random_B(a.n, k, 92)
@@ -854,7 +859,7 @@ def block_dense_graph(n, block, fill, noise_deg, seed):
 
 
 @pytest.mark.parametrize("k", [128, 32, 100, 256, 7])
-def test_mfma_dense_tile_route_matches_oracle(monkeypatch, k):
+def test_mfma_dense_tile_route_matches_oracle(knobs, k):
     """north_star: "MFMA only where ... reordering yields dense block-sparse tiles".  On a block-dense input the planner's
     detector routes the dense 32x32 tiles to the v_mfma_f32_32x32x2_f32 kernel and the rest to the vector kernel; the sum
     must pass resCheck against the oracle, be reproducible, and agree with the vector-only plan of the same matrix."""
@@ -868,13 +873,13 @@ def test_mfma_dense_tile_route_matches_oracle(monkeypatch, k):
     C1 = run_plan(p, B)
     assert_matches_oracle(a, B, C1)
     assert np.array_equal(C1, run_plan(p, B))
-    monkeypatch.setenv("FLEX_MFMA", "2")
+    knobs.set(mfma=2)
     pv = Plan(a, k, order=FLEX_ORDER_NATURAL | flex_amd.FLEX_PLAN_STATS)
     assert pv.info()["n_tiles"] == 0 and pv.stats()["tile_nnz_pct_50"] > 70.0   # the detector still reports, nothing is routed
     assert oracle.rescheck(run_plan(pv, B), C1, a.rowPtr)[0] == 0
 
 
-def test_mfma_route_after_reordering_shards_strides_and_duplicates(monkeypatch):
+def test_mfma_route_after_reordering_shards_strides_and_duplicates(knobs):
     """The detector works in SCHEDULE coordinates: a shuffled block-dense graph has no dense tile in natural order and
     plenty after the community ordering; mapped plans, row shards, padded storage and duplicate entries go through."""
     a0 = block_dense_graph(8000, 32, 0.8, 4, seed=5)
@@ -889,8 +894,8 @@ def test_mfma_route_after_reordering_shards_strides_and_duplicates(monkeypatch):
     del inv
     k = 128
     B = random_B(a.n, k, 4)
-    monkeypatch.setenv("FLEX_MFMA", "1")
-    monkeypatch.setenv("FLEX_MFMA_FILL", "25")  # communities do not start on tile boundaries: a block straddles tiles
+    knobs.set(mfma=1)
+    knobs.set(mfma_fill_pct=25)  # communities do not start on tile boundaries: a block straddles tiles
     nat = Plan(a, k, order=FLEX_ORDER_NATURAL)
     clu = Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER)
     assert nat.info()["tile_nnz"] < 0.05 * a.nnz < 0.3 * a.nnz < clu.info()["tile_nnz"]

@@ -83,20 +83,19 @@ def test_ragged_shapes_shards_maps_and_strides(sim):
 
 
 @pytest.mark.parametrize("lanes,k", [(8, 32), (8, 128), (16, 128), (32, 128), (64, 256)])
-def test_two_d_plans_are_partitions(sim, monkeypatch, lanes, k):
+def test_two_d_plans_are_partitions(sim, lanes, k):
     a = flex_amd.synth_graph(n=6000, nnz=6000 + 2 * 90000, community=200, p_in=0.55, p_near=0.3, seed=5)
-    monkeypatch.setenv("FLEX_2D", "1")
-    monkeypatch.setenv("FLEX_PANEL_KB", "32")
-    monkeypatch.setenv("FLEX_SEG_MIN", "2")
-    monkeypatch.setenv("FLEX_LANES", str(lanes))
+    knobs = {"two_d": 1, "panel_kb": 32, "seg_min": 2, "lanes_per_nz": lanes}
     for order in (flex_amd.FLEX_ORDER_NATURAL, flex_amd.FLEX_ORDER_CLUSTER):
-        p = flex_amd.Plan(a, k, order=order)
+        p = flex_amd.Plan(a, k, order=order, tuning=knobs)
+        t = p.tuning()
+        assert all(t[key] == v for key, v in knobs.items()), t
         info = p.info()
         assert info["two_d"] == 1 and info["lanes_per_nz"] == lanes and info["n_split_rows"] > a.m // 2
         p.self_check()
 
 
-def test_dense_tile_route_is_consistent(sim, monkeypatch):
+def test_dense_tile_route_is_consistent(sim):
     a = block_dense(6400, 64, 0.85, 5, seed=2)
     p = flex_amd.Plan(a, 128, order=flex_amd.FLEX_ORDER_NATURAL | flex_amd.FLEX_PLAN_STATS)
     info, st = p.info(), p.stats()
@@ -104,18 +103,14 @@ def test_dense_tile_route_is_consistent(sim, monkeypatch):
     assert abs(st["mfma_nnz_pct"] - 100.0 * info["tile_nnz"] / a.nnz) < 1e-9 and st["tile_nnz_pct_50"] >= st["mfma_nnz_pct"] - 1e-9
     assert st["records"] + info["tile_nnz"] >= a.nnz
     p.self_check()
-    monkeypatch.setenv("FLEX_MFMA", "2")
-    p2 = flex_amd.Plan(a, 128, order=flex_amd.FLEX_PLAN_STATS)
+    p2 = flex_amd.Plan(a, 128, order=flex_amd.FLEX_PLAN_STATS, tuning={"mfma": 2})
     assert p2.info()["n_tiles"] == 0 and p2.stats()["tile_nnz_pct_50"] == st["tile_nnz_pct_50"]  # the report does not depend on the route
-    monkeypatch.setenv("FLEX_MFMA", "1")
-    monkeypatch.setenv("FLEX_MFMA_FILL", "25")
+    route = {"mfma": 1, "mfma_fill_pct": 25}
     # a tile row that hangs over the end of the matrix, a shard, and a 2-D plan on top of the route
     odd = block_dense(1000, 40, 0.9, 3, seed=4)
-    flex_amd.Plan(odd, 64).self_check()
-    flex_amd.Plan(odd, 64, rows=(100, 777)).self_check()
-    monkeypatch.setenv("FLEX_2D", "1")
-    monkeypatch.setenv("FLEX_PANEL_KB", "16")
-    p3 = flex_amd.Plan(a, 128)
+    flex_amd.Plan(odd, 64, tuning=route).self_check()
+    flex_amd.Plan(odd, 64, rows=(100, 777), tuning=route).self_check()
+    p3 = flex_amd.Plan(a, 128, tuning=dict(route, two_d=1, panel_kb=16))
     assert p3.info()["two_d"] == 1 and p3.info()["n_tiles"] > 0
     p3.self_check()
 
@@ -144,26 +139,80 @@ def test_xcd_slices_are_a_rule_per_ordering_and_a_flag_for_reordered_loaders(sim
         flex_amd.Plan(a, 128, order=0x4000)  # unknown flag bits are refused
 
 
-def test_planner_result_does_not_depend_on_the_thread_count(sim, monkeypatch):
+def test_planner_result_does_not_depend_on_the_thread_count(sim):
     """The whole device image -- every byte the planner uploads, fingerprinted by the shim -- for 1, 3 and 8 host threads:
     1-D with the community ordering, the 2-D schedule, and the dense-tile route."""
     sim.hostsim_upload_hash.restype = C.c_uint64
     sim.hostsim_upload_hash.argtypes = [C.c_int]
     a = flex_amd.synth_graph(n=20000, nnz=20000 + 2 * 400000, community=256, p_in=0.6, p_near=0.25, seed=9)
     bd = block_dense(4096, 64, 0.8, 6, seed=2)
-    cases = [(a, {}), (a, {"FLEX_2D": "1"}), (bd, {"FLEX_MFMA": "1", "FLEX_MFMA_FILL": "50"}), (bd, {"FLEX_2D": "1", "FLEX_MFMA": "1"})]
+    cases = [(a, {}), (a, {"two_d": 1}), (bd, {"mfma": 1, "mfma_fill_pct": 50}), (bd, {"two_d": 1, "mfma": 1})]
     for g, env in cases:
-        for name in ("FLEX_2D", "FLEX_MFMA", "FLEX_MFMA_FILL"):
-            monkeypatch.delenv(name, raising=False)
-        for name, v in env.items():
-            monkeypatch.setenv(name, v)
         shapes = []
-        for threads in ("1", "3", "8"):
-            monkeypatch.setenv("FLEX_HOST_THREADS", threads)
+        for threads in (1, 3, 8):
             sim.hostsim_upload_hash(1)
-            p = flex_amd.Plan(g, 128, order=flex_amd.FLEX_ORDER_CLUSTER | flex_amd.FLEX_PLAN_STATS)
+            p = flex_amd.Plan(g, 128, order=flex_amd.FLEX_ORDER_CLUSTER | flex_amd.FLEX_PLAN_STATS, tuning=dict(env, host_threads=threads))
+            assert p.tuning()["host_threads"] == threads
             image = sim.hostsim_upload_hash(1)
             p.self_check()
             i, s = p.info(), p.stats()
             shapes.append((image, i["n_tasks"], i["n_chunks"], i["n_slots"], i["n_partials"], i["n_records"], i["n_tiles"], s["cols_wave"], s["cols_xcd"], s["chunk_rec_max"]))
         assert shapes[0] == shapes[1] == shapes[2], env
+
+
+def test_knobs_travel_in_the_descriptor_not_in_the_environment(sim, monkeypatch):
+    """ABI 3: plan-time knobs are fields of flex_plan_tuning.  The environment variables of rounds 1-2 are ignored; two
+    threads creating plans with DIFFERENT knobs at the same time each get their own (the getenv form was process-global)."""
+    import threading
+    a = flex_amd.synth_graph(n=6000, nnz=6000 + 2 * 90000, community=200, p_in=0.55, p_near=0.3, seed=5)
+    monkeypatch.setenv("FLEX_LANES", "8")
+    monkeypatch.setenv("FLEX_2D", "1")
+    monkeypatch.setenv("FLEX_FUSED_FIXUP", "1")
+    p = flex_amd.Plan(a, 128)
+    t = p.tuning()
+    assert p.info()["two_d"] == 0 and t["lanes_per_nz"] == 16 and t["split_rows"] == 2  # rules, whatever the environment says
+    # the default is the two-launch sum of split rows; the in-launch form has to be asked for
+    assert flex_amd.Plan(a, 128, tuning={"split_rows": 1}).tuning()["split_rows"] == 1
+    got, errs = {}, []
+    def make(name, knobs, rounds=6):
+        try:
+            for _ in range(rounds):
+                q = flex_amd.Plan(a, 128, order=flex_amd.FLEX_ORDER_CLUSTER, tuning=knobs)
+                q.self_check()
+                i, tq = q.info(), q.tuning()
+                got.setdefault(name, set()).add((i["lanes_per_nz"], i["two_d"], tq["chunk_records"], tq["host_threads"], i["n_chunks"]))
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=make, args=("x", {"lanes_per_nz": 8, "two_d": 1, "panel_kb": 32, "chunk_records": 96, "host_threads": 2})),
+          threading.Thread(target=make, args=("y", {"lanes_per_nz": 32, "chunk_records": 192, "host_threads": 3}))]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    assert not errs, errs
+    assert len(got["x"]) == 1 and len(got["y"]) == 1, got  # same plan every time, however the two threads interleaved
+    (gx, twx, cx, hx, _), = got["x"]
+    (gy, twy, cy, hy, _), = got["y"]
+    assert (gx, twx, cx, hx) == (8, 1, 96, 2) and (gy, twy, cy, hy) == (32, 0, 192, 3)
+    # nonsense is refused, not clamped
+    with pytest.raises(flex_amd.FlexError):
+        flex_amd.Plan(a, 128, tuning={"chunk_records": -5})
+    with pytest.raises(flex_amd.FlexError, match="unknown tuning knob"):
+        flex_amd.Plan(a, 128, tuning={"wave_nnz": 5})
+
+
+def test_descriptor_without_the_range_flag_refuses_a_range(sim):
+    """A shard range in a descriptor that lacks FLEX_PLAN_ROW_RANGE (a caller that forgot the flag, or was built before it
+    existed) used to give a plan over ALL rows -- and flex_spmm would then write past the shard's C buffer."""
+    a = random_csr(300, 300, 6, seed=2)
+    v = a.view()
+    L = binding.lib()
+    for begin, end in ((10, 50), (0, 50), (7, 0)):
+        d = binding._PlanDesc(C.sizeof(binding._PlanDesc), C.pointer(v), 32, 0, 0, 0, 0, begin, end, None, None, None)
+        h = C.c_void_p()
+        assert L.flex_plan_create_ex(C.byref(h), C.byref(d)) == -1
+    # a caller built against ABI 2 passes the shorter struct (no tuning member): still accepted
+    d = binding._PlanDesc(binding._PlanDesc.tuning.offset, C.pointer(v), 32, 0, 0, 0, 0, 0, 0, None, None, None)
+    h = C.c_void_p()
+    assert L.flex_plan_create_ex(C.byref(h), C.byref(d)) == 0
+    L.flex_plan_destroy(h)

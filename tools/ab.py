@@ -12,6 +12,7 @@ sys.path.insert(0, %r)
 from flex_amd import binding
 binding._SO = sys.argv[1]
 import flex_amd
+import tools._knobs  # noqa: F401  (FLEX_* environment knobs -> plan descriptor)
 name, k, order = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 a = flex_amd.synth_graph(name)
 B = torch.rand((a.n, k), device="cuda") * 2 - 1

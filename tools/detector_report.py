@@ -7,6 +7,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import flex_amd  # noqa: E402
+import tools._knobs  # noqa: E402,F401  (FLEX_* environment knobs -> plan descriptor)
 
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "pubmed.csv")
 print(f"{'graph':28s} {'order':8s} {'mean fill':>9s} {'>=0.10':>8s} {'>=0.25':>8s} {'>=0.50':>8s} {'MFMA tiles':>10s} {'routed nnz':>10s}")

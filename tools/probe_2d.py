@@ -11,6 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import flex_amd  # noqa: E402
+import tools._knobs  # noqa: E402,F401  (FLEX_* environment knobs -> plan descriptor)
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "reddit"
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 128

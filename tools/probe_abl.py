@@ -8,6 +8,7 @@ sys.path.insert(0, %r)
 from flex_amd import binding
 binding._SO = sys.argv[1]
 import flex_amd
+import tools._knobs  # noqa: F401  (FLEX_* environment knobs -> plan descriptor)
 name, k, fold = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 a = flex_amd.synth_graph(name)
 if fold: a = flex_amd.HostCsr(a.rowPtr, (a.col %% fold).astype(np.uint32), a.vals, n=a.n)

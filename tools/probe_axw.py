@@ -8,6 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import flex_amd  # noqa: E402
+import tools._knobs  # noqa: E402,F401  (FLEX_* environment knobs -> plan descriptor)
 from flex_amd import axw  # noqa: E402
 
 name, dim, c = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])

@@ -11,6 +11,7 @@ code = r'''
 import os, sys, torch
 sys.path.insert(0, %r)
 import flex_amd
+import tools._knobs  # noqa: F401  (FLEX_* environment knobs -> plan descriptor)
 n, deg, k = int(sys.argv[1]), float(sys.argv[2]), int(sys.argv[3])
 p = flex_amd.synth_preset("reddit")
 a = flex_amd.synth_graph(n=n, nnz=n + 2 * int(n * (deg - 1) / 2), alpha=p.alpha, community=p.community, p_in=p.p_in, p_near=p.p_near,

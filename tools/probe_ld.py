@@ -7,6 +7,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import flex_amd  # noqa: E402
+import tools._knobs  # noqa: E402,F401  (FLEX_* environment knobs -> plan descriptor)
 
 for name in ("flickr", "reddit"):
     a = flex_amd.synth_graph(name)

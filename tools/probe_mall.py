@@ -7,6 +7,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: F401,E402  (HIP runtime first)
 import flex_amd  # noqa: E402
+import tools._knobs  # noqa: E402,F401  (FLEX_* environment knobs -> plan descriptor)
 
 for mib in (8, 16, 32, 64, 96, 128, 192, 256, 384, 512, 1024, 2048, 4096):
     reps = 40 if mib <= 512 else 10

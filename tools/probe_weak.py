@@ -5,6 +5,7 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import flex_amd
+import tools._knobs  # noqa: F401  (FLEX_* environment knobs -> plan descriptor)
 name = sys.argv[1] if len(sys.argv) > 1 else "flickr"
 strong = len(sys.argv) > 2 and sys.argv[2] == "strong"  # fixed graph, rows/N per GPU (the north_star's Amazon run)
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 128

@@ -12,6 +12,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import flex_amd, oracle
+import tools._knobs  # noqa: E402,F401  (FLEX_* environment knobs -> plan descriptor)
 from flex_amd import HostCsr, Plan
 from util import random_csr
 
@@ -28,7 +29,7 @@ KNOBS = {
     "FLEX_SEG_MIN": [None, "1", "8"],
     "FLEX_MFMA": [None, None, "1", "2"],
     "FLEX_MFMA_FILL": [None, "5", "30", "90"],
-    "FLEX_FUSED_FIXUP": [None, None, None, "2"],
+    "FLEX_FUSED_FIXUP": [None, None, "1", "2"],  # 1 = in-launch (opt-in since ABI 3), 2 = two launches (default)
     "FLEX_REC_NT": [None, "1", "2"],
     "FLEX_U": [None, None, "8"],
     "FLEX_XCD_REMAP": [None, "1", "2"],

@@ -11,6 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import flex_amd  # noqa: E402
+import tools._knobs  # noqa: E402,F401  (FLEX_* environment knobs -> plan descriptor)
 from flex_amd import binding  # noqa: E402
 
 binding._SO = os.path.join(ROOT, "flex_amd", "lib", "libflex_spmm_trace.so")
