@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--no-vendor", action="store_true", help="skip the hipSPARSE side-by-side (N=1 only)")
     ap.add_argument("--check", action="store_true", help="verify rank 0's shard against the oracle (small workloads)")
     ap.add_argument("--shrink", type=int, default=1, help="rehearsals only: the preset with n and nnz divided by this (same generator and code path)")
+    ap.add_argument("--tuning", default="", help="plan-time knobs, fields of flex_plan_tuning: e.g. blocks=1,block_rounds=4 (experiments; default: the planner's rules)")
     ap.add_argument("--init-timeout", type=float, default=600.0, help="seconds to wait for the other ranks at start-up before failing (non-zero exit)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU, nothing measured: every rank runs the host side of the N-GPU path (same graph, same re-ordering, "
@@ -133,15 +134,16 @@ def main():
     order = {"cluster": flex_amd.FLEX_ORDER_CLUSTER, "rcm": flex_amd.FLEX_ORDER_RCM,
              "natural": flex_amd.FLEX_ORDER_NATURAL}[args.order]
     want_stats = False
+    tuning = {kv.split("=")[0].strip(): int(kv.split("=")[1]) for kv in args.tuning.split(",") if kv.strip()} or None
     if world == 1 and not args.dry_run:
         want_stats = a.nnz <= 50_000_000  # one extra pass over the records: skipped on amazon-size inputs
         plan = flex_amd.Plan(a, k, device=local_rank, order=order | (flex_amd.FLEX_PLAN_STATS if want_stats else 0)
-                             | (flex_amd.FLEX_PLAN_AUTOTUNE if args.autotune else 0))
+                             | (flex_amd.FLEX_PLAN_AUTOTUNE if args.autotune else 0), tuning=tuning)
         shard_nnz, shard_rows = a.nnz, a.m
         shard = None
     else:
         shard = flex_amd.make_shard(a, k, rank, world, order=args.order)
-        plan = None if args.dry_run else shard.plan(k, local_rank)
+        plan = None if args.dry_run else shard.plan(k, local_rank, tuning=tuning)
         shard_nnz, shard_rows = shard.nnz, shard.r1 - shard.r0
     t_plan = time.perf_counter() - t_plan
     info = plan.info() if plan is not None else {"n_chunks": 0, "n_tasks": 0, "n_split_rows": 0, "lanes_per_nz": 0, "two_d": 0, "n_tiles": 0}

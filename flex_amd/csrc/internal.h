@@ -44,6 +44,43 @@ struct TileView {
     uint32_t n_row_tiles;
 };
 
+// ---- the row-block path (block_kernels.hip, block_plan.cpp): LDS-level reuse of B.
+// A BLOCK is R = rounds x 120 row slots of schedule-consecutive rows, owned by ONE workgroup of 16 waves (15 consumer waves x 8
+// slots of 8 lanes + 1 loader wave).  Columns that at least `thr` nonzeros of the block use are HOT: their B rows (one 32-column
+// tile = 128 bytes each) are staged panel by panel into LDS by the loader wave (LDS-DMA, double-buffered) and every use reads
+// them with ds_read_b128; the block's other nonzeros (COLD) gather from global memory as the flat kernel does.  A slot walks ONE
+// row (or one part of a long row) through all phases with its sum in registers, so C is written once and nothing is combined
+// across workgroups.
+constexpr int kBkWaves = 15;                              // consumer waves per workgroup
+constexpr int kBkSlots = 8;                               // slots per wave (8 lanes x float4 = one 32-column tile of one row)
+constexpr int kBkRowsPerRound = kBkWaves * kBkSlots;      // 120 row slots per round
+constexpr int kBkMaxRounds = 8;
+constexpr uint32_t kBkPanelMax = 480;                     // B rows per LDS panel
+constexpr uint32_t kBkRowBytes = 128;                     // one B row of one column tile
+constexpr uint32_t kBkZeroRow = kBkPanelMax * kBkRowBytes; // byte offset, inside a panel buffer, of a row of zeros (padding records point at it)
+constexpr uint32_t kBkBufBytes = kBkZeroRow + kBkRowBytes;
+constexpr uint32_t kBkWinSteps = 32;                      // record window per consumer wave: 32 steps x 8 slots x 8 bytes = 2 KiB
+constexpr uint32_t kBkLdsWin = 2 * kBkBufBytes;
+constexpr uint32_t kBkLdsHcol = kBkLdsWin + kBkWaves * kBkWinSteps * kBkSlots * 8;
+constexpr uint32_t kBkLdsBytes = kBkLdsHcol + 2 * kBkPanelMax * 4;  // 157 696 of the CU's 163 840
+constexpr uint32_t kBkEmptyRow = 0x1FFFFFFFu;             // brow entry of a slot that holds no row
+constexpr uint32_t kBkMaxCounts = 256;                    // (1 + panels) x rounds step counts per wave, two per lane-held word
+
+struct BlockView {
+    const uint4 *hdr;        // [n_blocks] {panels | hub flag << 31, first entry in hcol, first word in cnt, words of cnt per wave}
+    const uint2 *wstart;     // [n_blocks][15] {first step of the wave's record stream, its steps}
+    const uint32_t *cnt;     // per (block, wave): 16-bit step counts, phase-major [1 + panels][rounds], two per word
+    const uint32_t *hcol;    // per (block, panel): panel_rows byte offsets of the B rows staged (padded with a valid one)
+    const uint32_t *brow;    // [n_blocks][rounds][15][8] C row of the slot (bits 0-28) | log2(slots of its row) << 29; kBkEmptyRow = none
+    const uint32_t *bgrp;    // [n_blocks][rounds][15] 0, or for a group that holds one of the g >= 2 parts of a HUB row (a row spread over g whole
+                             // groups on g waves): part | g << 8 | (first scratch slot of the row) << 16; hdr.x bit 31 says the block has such rows
+    const uint2 *rec;        // [steps][8] {cold phase: byte offset of the B row; panel phases: byte offset inside the panel buffer, value bits}
+    uint32_t n_blocks, rounds, panel_rows;
+    int32_t k, ldb, ldc;
+    uint32_t xcd_remap;
+    uint32_t ablate;         // timing-only (tools/probe_blocks.py; results are WRONG): 1 no panel DMA, 2 no panel-phase work, 4 no cold-phase work
+};
+
 constexpr uint32_t kPartialFlag = 0x80000000u;
 constexpr int kWavesPerBlock = 4;  // 256-thread workgroups
 constexpr int kXcds = 8;           // MI355X: 8 XCDs, each with a private 4 MiB L2
@@ -69,6 +106,7 @@ int launch_fixup(const float *partial, const SplitRow *rows, uint32_t n_rows, in
 int kernel_attributes(int lanes_per_nz, bool off32, bool vec4, hipFuncAttributes *attr, int *waves_per_cu);
 int launch_gather_rows(float *dst, const float *src, const int32_t *idx, int64_t n, int k, hipStream_t s);
 int launch_tiles(const TileView &tv, bool off32, const float *dB, float *dC, int k, int ldb, int ldc, hipStream_t s);
+int launch_blocks(const BlockView &bv, const float *dB, float *dC, hipStream_t s);
 
 // FLEX_PLAN_TIMING in the environment: phase times of the planner and the clustering on stderr.  The only environment
 // variable the library reads; every tuning knob is a field of flex_plan_tuning (include/flex_spmm.h).

@@ -64,6 +64,13 @@ void free_plan_device(flex_plan *p) {
     (void)hipFree(p->d_tile_boff);
     (void)hipFree(p->d_rt_ptr);
     (void)hipFree(p->d_rt_rows);
+    (void)hipFree(p->d_bk_hdr);
+    (void)hipFree(p->d_bk_wstart);
+    (void)hipFree(p->d_bk_cnt);
+    (void)hipFree(p->d_bk_hcol);
+    (void)hipFree(p->d_bk_brow);
+    (void)hipFree(p->d_bk_grp);
+    (void)hipFree(p->d_bk_rec);
 }
 
 }  // namespace flex
@@ -258,7 +265,16 @@ int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream) {
     const bool vec4 = operands_vec4(p, dB, dC);
     const bool fused = vec4 && p->fused_fixup;  // the generic kernel always leaves the sum to spmm_fixup_kernel
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    int rc = launch_spmm(plan_view(p, fused, p->trace), p->lanes_per_nz, p->off32, vec4, dB, dC, s, p->unroll);
+    int rc = FLEX_OK;
+    if (p->bk_blocks) {  // the rows owned by row blocks (their own kernel); everything below handles the other rows
+        // block plans exist for the float4 path only, and that needs the 16-byte alignment this header asks for
+        rc = vec4 ? launch_blocks(block_view(p), dB, dC, s) : FLEX_ERR_UNSUPPORTED;
+        if (rc) {
+            if (cur != p->device) (void)hipSetDevice(cur);
+            return rc;
+        }
+    }
+    rc = launch_spmm(plan_view(p, fused, p->trace), p->lanes_per_nz, p->off32, vec4, dB, dC, s, p->unroll);
     if (rc == FLEX_OK && !fused) rc = launch_fixup(p->d_partial, p->d_split, p->n_split, p->k, p->ldc, dC, s);
     // the dense tiles' share, added to the rows the kernels above have written
     if (rc == FLEX_OK && p->n_tiles) rc = launch_tiles(tile_view(p), p->off32, dB, dC, p->k, p->ldb, p->ldc, s);
@@ -298,6 +314,13 @@ int flex_plan_get_info(const flex_plan *p, flex_plan_info *o) {
     o->tile_nnz = p->tile_nnz;
     o->n_records = static_cast<int64_t>(p->n_records);
     o->panel_rows = p->two_d ? static_cast<int32_t>(p->panel_rows) : 0;
+    o->n_blocks = p->bk_blocks;
+    o->block_rows = p->bk_rows;
+    o->block_nnz = p->bk_nnz;
+    o->block_hot_nnz = p->bk_hot_nnz;
+    o->block_hot_cols = p->bk_hot_cols;
+    o->block_panels = p->bk_panels;
+    o->block_records = p->bk_records;
     return FLEX_OK;
 }
 

@@ -43,6 +43,12 @@ struct flex_plan {
     int64_t tile_hist[3] = {0, 0, 0}, tile_cells = 0;  // detector report
     bool tile_hist_valid = false;
     uint32_t panel_rows = 0;
+    // row blocks (block_kernels.hip): the rows they own are not in the task / chunk arrays above
+    uint4 *d_bk_hdr = nullptr;
+    uint2 *d_bk_wstart = nullptr, *d_bk_rec = nullptr;
+    uint32_t *d_bk_cnt = nullptr, *d_bk_hcol = nullptr, *d_bk_brow = nullptr, *d_bk_grp = nullptr;
+    uint32_t bk_blocks = 0, bk_rounds = 0, bk_panel_rows = 0, bk_ablate = 0;
+    int64_t bk_rows = 0, bk_nnz = 0, bk_hot_nnz = 0, bk_hot_cols = 0, bk_panels = 0, bk_records = 0;
     uint32_t n_tasks = 0, n_chunks = 0, n_slots = 0, n_split = 0, n_partials = 0;  // n_slots: chunk table incl. padding
     uint64_t n_records = 0;   // nnz + padding
     int64_t c_rows = 0;       // rows of C the plan writes into (m, or hostA->m for a mapped plan)
@@ -94,6 +100,10 @@ inline PlanView plan_view(const flex_plan *p, bool fused, uint64_t *trace) {
                     fused ? 1u : 0u, p->n_slots, p->k, p->ldb, p->ldc,
                     p->xcd_remap ? 1u : 0u, p->lds_extra, p->rec_nt ? 1u : 0u, trace};
 }
+inline BlockView block_view(const flex_plan *p) {
+    return BlockView{p->d_bk_hdr, p->d_bk_wstart, p->d_bk_cnt, p->d_bk_hcol, p->d_bk_brow, p->d_bk_grp, p->d_bk_rec, p->bk_blocks, p->bk_rounds, p->bk_panel_rows,
+                     p->k, p->ldb, p->ldc, 1u, p->bk_ablate};
+}
 inline TileView tile_view(const flex_plan *p) { return TileView{p->d_tile_a, p->d_tile_boff, p->d_rt_ptr, p->d_rt_rows, p->n_row_tiles}; }
 // float4 path: k and both strides multiples of 4, both base addresses 16-byte aligned
 inline bool operands_vec4(const flex_plan *p, const float *dB, const float *dC) {
@@ -121,6 +131,22 @@ struct DenseTiles {
 int detect_dense_tiles(const flex_csr *A, int32_t r0, int32_t m, const std::vector<uint32_t> &sched, const std::vector<uint32_t> &colpos,
                        const int32_t *col_map, const int32_t *dst_map, bool off32, uint32_t row_bytes32, uint32_t thr, int64_t stride,
                        std::vector<uint8_t> &in_tile, DenseTiles &out);
+
+// ---- row blocks (block_plan.cpp)
+struct BlockKnobs {
+    uint32_t rounds = 4, panel_rows = kBkPanelMax, thr = 2, cap = 512, max_panels = 30, min_last_panel = 64;
+};
+struct BlockImage {  // host copy of what BlockView points at
+    std::vector<uint4> hdr;
+    std::vector<uint2> wstart;
+    std::vector<uint32_t> cnt, hcol, brow, grp;
+    RecordVec rec;
+    uint32_t n_blocks = 0, rounds = 0, panel_rows = 0;
+    int64_t rows = 0, nnz = 0, hot_nnz = 0, hot_cols = 0, panels = 0;
+};
+// Rows sched[0..) of A (a row's C row: dst_map, or r - r0) into blocks; `rest` receives the schedule positions that stay flat.
+int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const std::vector<uint32_t> &colpos, const int32_t *col_map,
+                 const int32_t *dst_map, int32_t r0, uint32_t row_bytes32, const BlockKnobs &kn, BlockImage &img, std::vector<uint32_t> &rest);
 
 // ---- plan_check.cpp
 void collect_stats(flex_plan *p, const RecordVec &rec, const std::vector<uint4> &chunk, int64_t split_nnz);

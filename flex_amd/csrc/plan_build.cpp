@@ -51,6 +51,18 @@ class PlanBuilder {
           flags(flags_), order(flags_ & FLEX_ORDER_MASK), force_G(force_G_), tn(tuning), sched(sched_cache_ ? *sched_cache_ : sched_local),
           have_cache(sched_cache_ != nullptr), timing(plan_timing_enabled()), t_last(std::chrono::steady_clock::now()) {}
 
+    // The first two stages alone, for the row-block route (build_plan below): the schedule and its inverse.
+    int schedule_only(std::vector<uint32_t> **sched_out, std::vector<uint32_t> **colpos_out) {
+        if (order > FLEX_ORDER_GORDER) return FLEX_ERR_INVALID;
+        if (order != FLEX_ORDER_NATURAL && (A->m != A->n || r0 != 0 || r1 != A->m)) return FLEX_ERR_INVALID;
+        choose_tile_width();
+        const int rc = order_rows();
+        lap("row schedule");
+        *sched_out = &sched;
+        *colpos_out = &colpos;
+        return rc;
+    }
+
     int run() {
         if (order > FLEX_ORDER_GORDER) return FLEX_ERR_INVALID;
         // graph orderings need the whole square matrix
@@ -670,8 +682,94 @@ class PlanBuilder {
 
 }  // namespace
 
+// The row-block route: rows go to blocks (block_plan.cpp: one workgroup each, hot B rows staged in LDS); what the
+// blocks do not take -- empty rows, rows longer than 8 x cap -- becomes a small CSR of its own, in schedule order, with a
+// row map, and is planned by the flat planner as a natural-order plan into the same flex_plan.
+static int build_with_blocks(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const int32_t *col_map, const int32_t *dst_map, unsigned flags,
+                             const flex_plan_tuning &tuning, std::vector<uint32_t> *sched_cache) {
+    const int32_t m = r1 - r0;
+    std::vector<uint32_t> *sched = nullptr, *colpos = nullptr;
+    PlanBuilder pre(p, A, r0, r1, col_map, dst_map, flags, tuning, sched_cache, 0);
+    int rc = pre.schedule_only(&sched, &colpos);
+    if (rc) return rc;
+    BlockKnobs kn;
+    const int32_t rd = tuning.block_rounds;
+    if (rd == 1 || rd == 2 || rd == 4 || rd == 8) kn.rounds = static_cast<uint32_t>(rd);
+    else if (rd != 0) return FLEX_ERR_INVALID;
+    if (tuning.block_panel_rows) {
+        if (tuning.block_panel_rows % 8 != 0 || tuning.block_panel_rows > static_cast<int32_t>(kBkPanelMax)) return FLEX_ERR_INVALID;
+        kn.panel_rows = static_cast<uint32_t>(tuning.block_panel_rows);
+    }
+    if (tuning.block_thr) kn.thr = static_cast<uint32_t>(tuning.block_thr);
+    const double avg = m > 0 ? static_cast<double>(A->rowPtr[r1] - A->rowPtr[r0]) / m : 0.0;
+    // a slot may be about three average rows long before its row is spread over 2 / 4 / 8 slots (the wave that holds it is
+    // evened out against the others by the planner's longest-processing-time deal)
+    kn.cap = tuning.block_cap ? static_cast<uint32_t>(std::min<int32_t>(tuning.block_cap, 60000)) : static_cast<uint32_t>(std::clamp(3.0 * avg, 64.0, 4096.0));
+    kn.min_last_panel = std::min<uint32_t>(64, kn.panel_rows / 4);
+    BlockImage img;
+    std::vector<uint32_t> rest;
+    const uint32_t row_bytes32 = static_cast<uint32_t>(p->ldb) * 4u;
+    if ((rc = build_blocks(A, *sched, *colpos, col_map, dst_map, r0, row_bytes32, kn, img, rest))) return rc;
+    // upload the block image
+    if ((rc = upload(&p->d_bk_hdr, img.hdr, &p->device_bytes))) return rc;
+    if ((rc = upload(&p->d_bk_wstart, img.wstart, &p->device_bytes))) return rc;
+    if ((rc = upload(&p->d_bk_cnt, img.cnt, &p->device_bytes))) return rc;
+    if ((rc = upload(&p->d_bk_hcol, img.hcol, &p->device_bytes))) return rc;
+    if ((rc = upload(&p->d_bk_brow, img.brow, &p->device_bytes))) return rc;
+    if ((rc = upload(&p->d_bk_grp, img.grp, &p->device_bytes))) return rc;
+    if ((rc = upload(&p->d_bk_rec, img.rec, &p->device_bytes))) return rc;
+    p->bk_blocks = img.n_blocks;
+    p->bk_rounds = img.rounds;
+    p->bk_panel_rows = img.panel_rows;
+    p->bk_rows = img.rows;
+    p->bk_nnz = img.nnz;
+    p->bk_hot_nnz = img.hot_nnz;
+    p->bk_hot_cols = img.hot_cols;
+    p->bk_panels = img.panels;
+    p->bk_records = static_cast<int64_t>(img.rec.size());
+    p->bk_ablate = static_cast<uint32_t>(tuning.block_ablate);
+    img = BlockImage{};
+    // the rows that stay flat, as a CSR of their own (schedule order) with the C row of each
+    const size_t m_rest = rest.size();
+    std::vector<uint32_t> rp(m_rest + 1, 0u);
+    std::vector<int32_t> dst(m_rest + 1, 0);
+    for (size_t i = 0; i < m_rest; ++i) {
+        const uint32_t r = (*sched)[rest[i]];
+        rp[i + 1] = rp[i] + (A->rowPtr[r + 1] - A->rowPtr[r]);
+        dst[i] = dst_map ? dst_map[r] : static_cast<int32_t>(r) - r0;
+    }
+    std::vector<uint32_t> cc(std::max<size_t>(rp[m_rest], 1));
+    std::vector<float> vv(std::max<size_t>(rp[m_rest], 1));
+    for (size_t i = 0; i < m_rest; ++i) {
+        const uint32_t r = (*sched)[rest[i]];
+        std::copy(A->col + A->rowPtr[r], A->col + A->rowPtr[r + 1], cc.begin() + rp[i]);
+        std::copy(A->vals + A->rowPtr[r], A->vals + A->rowPtr[r + 1], vv.begin() + rp[i]);
+    }
+    const flex_csr A_rest{static_cast<int32_t>(m_rest), A->n, static_cast<int64_t>(rp[m_rest]), rp.data(), cc.data(), vv.data()};
+    const unsigned order = flags & FLEX_ORDER_MASK;
+    flex_plan_tuning t2 = tuning;
+    t2.mfma = 2;  // the dense-tile route and the block route do not combine (yet)
+    rc = PlanBuilder(p, &A_rest, 0, static_cast<int32_t>(m_rest), col_map, dst.data(), (flags & ~FLEX_ORDER_MASK) | FLEX_ORDER_NATURAL, t2, nullptr, 0).run();
+    if (rc) return rc;
+    p->order = order;
+    p->c_rows = dst_map ? A->m : m;
+    flex_plan_tuning &u = p->tuning;
+    u.blocks = 1;
+    u.block_rounds = static_cast<int32_t>(kn.rounds);
+    u.block_panel_rows = static_cast<int32_t>(kn.panel_rows);
+    u.block_thr = static_cast<int32_t>(kn.thr);
+    u.block_cap = static_cast<int32_t>(kn.cap);
+    return FLEX_OK;
+}
+
 int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const int32_t *col_map, const int32_t *dst_map, unsigned flags,
                const flex_plan_tuning &tuning, std::vector<uint32_t> *sched_cache, int force_G) try {
+    // Row blocks: on request only (tuning.blocks = 1) until the rule is measured; they need the float4 path's shapes, 32-bit
+    // B offsets, and no forced tile width (autotune candidates stay flat).
+    const bool block_shapes = p->k % 4 == 0 && p->ldb % 4 == 0 && p->ldc % 4 == 0 &&
+                              static_cast<uint64_t>(A->n) * static_cast<uint64_t>(p->ldb) * 4u <= (uint64_t(1) << 32);
+    if (tuning.blocks == 1 && block_shapes && force_G == 0 && r1 > r0 && tuning.mfma != 1 && tuning.two_d != 1)
+        return build_with_blocks(p, A, r0, r1, col_map, dst_map, flags, tuning, sched_cache);
     return PlanBuilder(p, A, r0, r1, col_map, dst_map, flags, tuning, sched_cache, force_G).run();
 } catch (const std::bad_alloc &) {  // any host allocation of any stage
     return FLEX_ERR_NOMEM;

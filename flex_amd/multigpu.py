@@ -36,9 +36,9 @@ class RowShard:
     def nnz(self) -> int:
         return int(self.a.rowPtr[self.r1]) - int(self.a.rowPtr[self.r0])
 
-    def plan(self, k: int, device: int) -> "_b.Plan":
+    def plan(self, k: int, device: int, tuning: dict | None = None) -> "_b.Plan":
         """Plan for this rank's rows; columns are mapped back through vo_mp so the un-permuted B is used."""
-        return _b.Plan(self.a, k, device=device, rows=(self.r0, self.r1), col_map=self.vo_mp)
+        return _b.Plan(self.a, k, device=device, rows=(self.r0, self.r1), col_map=self.vo_mp, tuning=tuning)
 
     def local_csr(self):
         """(rowPtr, col, vals) of this rank's slice with columns in ORIGINAL numbering (what the plan computes)."""

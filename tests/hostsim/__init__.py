@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _CSRC = os.path.join(_ROOT, "flex_amd", "csrc")
 _OUT = os.path.join(_HERE, "_build", "libflex_hostsim.so")
-HOST_SOURCES = ["plan.cpp", "plan_build.cpp", "plan_check.cpp", "dense_tiles.cpp", "ingest.cpp", "reorder.cpp", "cluster.cpp", "rabbit.cpp", "gorder.cpp", "shard.cpp", "synth.cpp"]
+HOST_SOURCES = ["plan.cpp", "plan_build.cpp", "block_plan.cpp", "plan_check.cpp", "dense_tiles.cpp", "ingest.cpp", "reorder.cpp", "cluster.cpp", "rabbit.cpp", "gorder.cpp", "shard.cpp", "synth.cpp"]
 
 
 def build(extra_flags=(), out=_OUT):

@@ -1,0 +1,139 @@
+"""GPU parity tests of the row-block path (LDS-staged B panels, block_kernels.hip) against the CPU oracle, through the C ABI.
+Same tolerance as everywhere: the reference's resCheck (flex.cu:4154-4213), zero mismatches."""
+import numpy as np
+import pytest
+
+import flex_amd
+import oracle
+from flex_amd import FLEX_ORDER_NATURAL, Plan
+from util import assert_matches_oracle, random_B, random_csr
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+
+
+def run_plan(plan, B):
+    C = plan(dev(B))
+    torch.cuda.synchronize()
+    return C.cpu().numpy()
+
+
+BLOCKS = {"blocks": 1}
+
+
+@pytest.mark.parametrize("k", [32, 128, 64, 100, 36, 4, 256])
+@pytest.mark.parametrize("order", [FLEX_ORDER_NATURAL, flex_amd.FLEX_ORDER_CLUSTER])
+def test_row_blocks_match_the_oracle(k, order):
+    """A community graph (most nonzeros hot), default knobs: resCheck against the oracle, same bits on a second launch and
+    from a second plan, and agreement with the flat plan of the same matrix within the tolerance."""
+    g = flex_amd.synth_graph(n=20000, nnz=20000 + 2 * 500000, community=400, p_in=0.6, p_near=0.25, seed=21)
+    B = random_B(g.n, k, 3)
+    p = Plan(g, k, order=order, tuning=BLOCKS)
+    i = p.info()
+    assert i["n_blocks"] >= 40 and i["block_rows"] > 0.9 * g.m
+    p.self_check()
+    C1 = run_plan(p, B)
+    assert_matches_oracle(g, B, C1)
+    assert np.array_equal(C1, run_plan(p, B))
+    assert np.array_equal(C1, run_plan(Plan(g, k, order=order, tuning=BLOCKS), B))
+    assert oracle.rescheck(run_plan(Plan(g, k, order=order), B), C1, g.rowPtr)[0] == 0
+
+
+@pytest.mark.parametrize("rounds,panel_rows,thr,cap", [(1, 64, 2, 40), (2, 128, 3, 24), (8, 480, 4, 0), (4, 8, 2, 16), (4, 480, 1, 0), (4, 480, 1000000, 0)])
+def test_row_blocks_over_the_knobs(rounds, panel_rows, thr, cap):
+    """Every shape of the block image: 1..8 rows per slot, tiny panels (many phases and barriers), thr = 1 (everything hot),
+    a threshold nothing reaches (everything cold: the block kernel as a pure gather kernel), small caps (long rows over 2 / 4 / 8
+    slots, hubs and empty rows left to the flat kernel)."""
+    a = random_csr(9000, 9000, 20, seed=31, long_rows={5: 8000, 77: 1200, 4000: 300, 8999: 150, 100: 90, 101: 41}, empty_frac=0.05)
+    knobs = dict(BLOCKS, block_rounds=rounds, block_panel_rows=panel_rows, block_thr=thr, block_cap=cap)
+    for k in (32, 128, 20):
+        B = random_B(a.n, k, 5)
+        p = Plan(a, k, tuning=knobs)
+        i = p.info()
+        assert i["n_blocks"] > 0
+        if thr == 1:
+            assert i["block_hot_nnz"] > 0.95 * i["block_nnz"]  # all but the few columns of an almost empty last panel
+        if thr == 1000000:
+            assert i["block_hot_nnz"] == 0 and i["block_panels"] == 0
+        p.self_check()
+        C = run_plan(p, B)
+        assert_matches_oracle(a, B, C)
+        assert np.array_equal(C, run_plan(p, B))
+
+
+def test_row_blocks_mapped_shards_strides_and_non_finite_values():
+    g = flex_amd.synth_graph(n=16000, nnz=16000 + 2 * 300000, community=256, p_in=0.6, p_near=0.25, seed=6)
+    k = 128
+    B = random_B(g.n, k, 5)
+    gold = oracle.spmm(g.rowPtr, g.col, g.vals, B, nthreads=8)
+    # the reference's flow (permuted loader + vo_mp) and three row shards of it
+    vo, gp = flex_amd.perm_csr(g, flex_amd.order_cluster(g))
+    pm = Plan(gp, k, vo_mp=vo, tuning=BLOCKS)
+    assert pm.info()["n_blocks"] > 0
+    assert oracle.rescheck(gold, run_plan(pm, B), g.rowPtr)[0] == 0
+    bounds = flex_amd.shard_rows(gp, k, 3)
+    got = np.zeros_like(gold)
+    for s in range(3):
+        ps = Plan(gp, k, rows=(bounds[s], bounds[s + 1]), col_map=vo, tuning=BLOCKS)
+        assert ps.info()["n_blocks"] > 0
+        ps.self_check()
+        got[vo[bounds[s]:bounds[s + 1]]] = run_plan(ps, B)
+    assert oracle.rescheck(gold, got, g.rowPtr)[0] == 0
+    # padded storage: the tail of every C row is left alone
+    ldb, ldc, kk = 96, 68, 64
+    Bs = random_B(g.n, ldb, 7)
+    Cd = torch.full((g.m, ldc), 2.5, device="cuda")
+    pl = Plan(g, kk, order=flex_amd.FLEX_ORDER_CLUSTER, ldb=ldb, ldc=ldc, tuning=BLOCKS)
+    assert pl.info()["n_blocks"] > 0
+    pl.spmm(dev(Bs).data_ptr(), Cd.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    Cs = Cd.cpu().numpy()
+    assert np.all(Cs[:, kk:] == 2.5)
+    assert_matches_oracle(g, np.ascontiguousarray(Bs[:, :kk]), np.ascontiguousarray(Cs[:, :kk]))
+    # inf / NaN in B reach exactly the rows that reference them (padding records point at a row of zeros, or at a column
+    # the row uses anyway)
+    Bn = B.copy()
+    bad = [3, 4000, 15999]
+    Bn[bad[0], 5] = np.inf
+    Bn[bad[1], :] = np.nan
+    Bn[bad[2], 77] = -np.inf
+    Cn = run_plan(Plan(g, k, order=flex_amd.FLEX_ORDER_CLUSTER, tuning=BLOCKS), Bn)
+    rows = np.repeat(np.arange(g.m), np.diff(g.rowPtr.astype(np.int64)))
+    touched = np.zeros(g.m, bool)
+    touched[rows[np.isin(g.col, bad)]] = True
+    assert np.all(np.isfinite(Cn[~touched])) and not np.all(np.isfinite(Cn[touched]))
+    clean = ~touched
+    assert oracle.rescheck(gold[clean], Cn[clean], np.concatenate([[0], np.cumsum(np.diff(g.rowPtr.astype(np.int64))[clean])]).astype(np.uint32))[0] == 0
+    # an unaligned C: block plans need the float4 path (documented), refused rather than computed wrongly
+    Cu = torch.empty(g.m * k + 1, device="cuda")[1:]
+    with pytest.raises(flex_amd.FlexError):
+        Plan(g, k, tuning=BLOCKS).spmm(dev(B).data_ptr(), Cu.data_ptr(), torch.cuda.current_stream().cuda_stream)
+
+
+def test_row_blocks_are_stable_under_repetition():
+    """Barriers and LDS hand-offs between the loader wave and the consumers: 200 launches under uneven load, same bits."""
+    g = flex_amd.synth_graph(n=60000, nnz=60000 + 2 * 2400000, community=1024, p_in=0.6, p_near=0.25, seed=8)
+    k = 128
+    Bn = random_B(g.n, k, 92)
+    B = dev(Bn)
+    p = Plan(g, k, order=flex_amd.FLEX_ORDER_CLUSTER, tuning=BLOCKS)
+    assert p.info()["block_panels"] > 2 * p.info()["n_blocks"]
+    ref = p(B).clone()
+    torch.cuda.synchronize()
+    assert_matches_oracle(g, Bn, ref.cpu().numpy(), nthreads=8)
+    C = torch.empty_like(ref)
+    filler = torch.empty(64 << 20, device="cuda")
+    for it in range(200):
+        C.fill_(float("nan"))
+        if it % 3 == 0:
+            filler.add_(1.0)
+        p(B, out=C)
+        if it % 25 == 24 or it < 4:
+            torch.cuda.synchronize()
+            assert torch.equal(C, ref), f"launch {it}: result changed"
+    torch.cuda.synchronize()
+    assert torch.equal(C, ref)

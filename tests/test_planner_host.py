@@ -216,3 +216,40 @@ def test_descriptor_without_the_range_flag_refuses_a_range(sim):
     h = C.c_void_p()
     assert L.flex_plan_create_ex(C.byref(h), C.byref(d)) == 0
     L.flex_plan_destroy(h)
+
+
+@pytest.mark.parametrize("rounds,panel_rows,thr,cap", [(4, 480, 2, 0), (1, 64, 2, 40), (2, 128, 3, 24), (8, 480, 4, 0), (4, 8, 2, 16)])
+def test_row_block_plans_are_partitions(sim, rounds, panel_rows, thr, cap):
+    """The row-block route (LDS-staged B panels): rows go to blocks of rounds x 120 slots, long rows take 2 / 4 / 8 aligned slots,
+    empty rows and rows beyond 8 x cap stay with the flat planner; the device image must be a partition of the work
+    (flex_plan_self_check reads the block tables and every record stream back) for every shape of the knobs."""
+    a = random_csr(9000, 9000, 20, seed=31, long_rows={5: 8000, 77: 1200, 4000: 300, 8999: 150}, empty_frac=0.05)
+    g = flex_amd.synth_graph(n=12000, nnz=12000 + 2 * 240000, community=300, p_in=0.6, p_near=0.25, seed=12)
+    knobs = {"blocks": 1, "block_rounds": rounds, "block_panel_rows": panel_rows, "block_thr": thr, "block_cap": cap}
+    for mat, order, k in ((a, flex_amd.FLEX_ORDER_NATURAL, 128), (g, flex_amd.FLEX_ORDER_CLUSTER, 32), (g, flex_amd.FLEX_ORDER_RCM, 100)):
+        p = flex_amd.Plan(mat, k, order=order, tuning=knobs)
+        p.self_check()
+        i, t = p.info(), p.tuning()
+        assert i["n_blocks"] > 0 and t["blocks"] == 1 and t["block_rounds"] == rounds and t["block_panel_rows"] == panel_rows
+        assert 0 < i["block_rows"] <= mat.m and i["block_nnz"] <= mat.nnz and i["block_records"] >= i["block_nnz"]
+        assert i["block_hot_nnz"] <= i["block_nnz"] and i["block_hot_cols"] <= i["block_panels"] * panel_rows
+        assert i["n_records"] + i["block_records"] >= mat.nnz  # flat part + blocks hold every nonzero
+        if mat is g and order == flex_amd.FLEX_ORDER_CLUSTER and rounds >= 4 and thr == 2 and panel_rows >= 64:
+            assert i["block_hot_nnz"] > 0.3 * mat.nnz  # the planted communities are found as hot columns
+    # shards and mapped plans go through the route too
+    vo, gp = flex_amd.perm_csr(g, flex_amd.order_cluster(g))
+    flex_amd.Plan(gp, 128, vo_mp=vo, tuning=knobs).self_check()
+    pb = flex_amd.Plan(gp, 64, rows=(1000, 7000), col_map=vo, tuning=knobs)
+    pb.self_check()
+    assert pb.info()["block_rows"] <= 6000
+    # shapes the block kernel does not take fall back to the flat plan silently
+    assert flex_amd.Plan(g, 7, tuning=knobs).info()["n_blocks"] == 0
+    # the same image for any number of host threads
+    sim.hostsim_upload_hash.restype = C.c_uint64
+    sim.hostsim_upload_hash.argtypes = [C.c_int]
+    images = []
+    for threads in (1, 5):
+        sim.hostsim_upload_hash(1)
+        flex_amd.Plan(g, 128, order=flex_amd.FLEX_ORDER_CLUSTER, tuning=dict(knobs, host_threads=threads))
+        images.append(sim.hostsim_upload_hash(1))
+    assert images[0] == images[1]

@@ -7,7 +7,7 @@ set -e
 cd "$(dirname "$0")/.."
 out=/tmp/flex_asan; mkdir -p $out
 SAN="-std=c++20 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined -fPIC -shared"
-SRC="flex_amd/csrc/plan.cpp flex_amd/csrc/plan_build.cpp flex_amd/csrc/plan_check.cpp flex_amd/csrc/dense_tiles.cpp flex_amd/csrc/ingest.cpp flex_amd/csrc/reorder.cpp flex_amd/csrc/cluster.cpp flex_amd/csrc/rabbit.cpp flex_amd/csrc/gorder.cpp \
+SRC="flex_amd/csrc/plan.cpp flex_amd/csrc/plan_build.cpp flex_amd/csrc/block_plan.cpp flex_amd/csrc/plan_check.cpp flex_amd/csrc/dense_tiles.cpp flex_amd/csrc/ingest.cpp flex_amd/csrc/reorder.cpp flex_amd/csrc/cluster.cpp flex_amd/csrc/rabbit.cpp flex_amd/csrc/gorder.cpp \
     flex_amd/csrc/shard.cpp flex_amd/csrc/synth.cpp tests/hostsim/shim.cpp"
 # (1) the library as the CPU suite sees it: no kernels, real HIP runtime (no device here: plans fail loudly)
 g++ $SAN -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iflex_amd/csrc -o $out/libflex_spmm.so $SRC -lpthread -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib

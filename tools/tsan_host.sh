@@ -28,6 +28,7 @@ namespace flex {
 int launch_spmm(const PlanView &, int, bool, bool, const float *, float *, hipStream_t, int) { return FLEX_ERR_UNSUPPORTED; }
 int launch_spmm_stamped(const PlanView &, int, bool, const float *, float *, hipStream_t) { return FLEX_ERR_UNSUPPORTED; }
 int launch_tiles(const TileView &, bool, const float *, float *, int, int, int, hipStream_t) { return FLEX_ERR_UNSUPPORTED; }
+int launch_blocks(const BlockView &, const float *, float *, hipStream_t) { return FLEX_ERR_UNSUPPORTED; }
 int launch_fixup(const float *, const SplitRow *, uint32_t, int, int, float *, hipStream_t) { return FLEX_ERR_UNSUPPORTED; }
 int launch_gather_rows(float *, const float *, const int32_t *, int64_t, int, hipStream_t) { return FLEX_ERR_UNSUPPORTED; }
 int kernel_attributes(int, bool, bool, hipFuncAttributes *, int *) { return FLEX_ERR_UNSUPPORTED; }
@@ -35,6 +36,6 @@ int kernel_attributes(int, bool, bool, hipFuncAttributes *, int *) { return FLEX
 extern "C" int flex_hbm_probe(int, int64_t, int, int, double *, double *) { return FLEX_ERR_UNSUPPORTED; }
 CPP
 g++ -std=c++20 -O1 -g -fsanitize=thread -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iflex_amd/csrc -o $out/t $out/main.cpp \
-    flex_amd/csrc/plan.cpp flex_amd/csrc/plan_build.cpp flex_amd/csrc/plan_check.cpp flex_amd/csrc/dense_tiles.cpp flex_amd/csrc/ingest.cpp flex_amd/csrc/reorder.cpp flex_amd/csrc/cluster.cpp flex_amd/csrc/rabbit.cpp \
+    flex_amd/csrc/plan.cpp flex_amd/csrc/plan_build.cpp flex_amd/csrc/block_plan.cpp flex_amd/csrc/plan_check.cpp flex_amd/csrc/dense_tiles.cpp flex_amd/csrc/ingest.cpp flex_amd/csrc/reorder.cpp flex_amd/csrc/cluster.cpp flex_amd/csrc/rabbit.cpp \
     flex_amd/csrc/gorder.cpp flex_amd/csrc/shard.cpp flex_amd/csrc/synth.cpp $out/shim.cpp -lpthread -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
 FLEX_HOST_THREADS=${FLEX_HOST_THREADS:-6} $out/t
