@@ -78,6 +78,19 @@ __device__ __forceinline__ void dma_panel(char *lds, const char *__restrict__ Bb
         __builtin_amdgcn_global_load_lds((gl_void *)(Bb + boff[g * 8] + lane_goff), (lds_void *)(dst + g * 1024), 16, 0, 0);
 }
 
+// Diagnostic build only (make -C flex_amd/csrc trace; tools/trace_blocks.py): where a wave's cycles go.  Counters per wave:
+// 0 prologue, 1 cold phase, 2 panel phases, 3 waiting at barriers, 4 window refills (also inside 1 and 2), 5 epilogue, 6 total.
+#ifdef FLEX_TRACE
+#define BK_STAMP(i)                                        \
+    do {                                                   \
+        const uint64_t now_ = __builtin_amdgcn_s_memtime(); \
+        bk_ph[i] += now_ - bk_last;                        \
+        bk_last = now_;                                    \
+    } while (0)
+#else
+#define BK_STAMP(i) do {} while (0)
+#endif
+
 template <int ROUNDS, int U_HOT, int U_COLD>
 __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_block_kernel(BlockView v, const float *__restrict__ B, float *__restrict__ C) {
     __shared__ __attribute__((aligned(128))) char lds[kBkLdsBytes];
@@ -100,7 +113,7 @@ __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_block_kernel(BlockVi
 
     if (w == kBkWaves) {
         // ---- the loader wave: per column tile np + 1 barriers, exactly as many as every consumer wave
-        if (lane < 32) {  // the rows of zeros that padding records point at; never written again
+        {  // the two rows of zeros (256 bytes) per buffer that padding records point at; never written again
             *reinterpret_cast<uint32_t *>(lds + kBkZeroRow + lane * 4) = 0u;
             *reinterpret_cast<uint32_t *>(lds + kBkBufBytes + kBkZeroRow + lane * 4) = 0u;
         }
@@ -128,6 +141,11 @@ __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_block_kernel(BlockVi
     }
 
     // ---- a consumer wave
+#ifdef FLEX_TRACE
+    uint64_t bk_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t bk_last = __builtin_amdgcn_s_memtime();
+    const uint64_t bk_t0 = bk_last;
+#endif
     const uint32_t slot = static_cast<uint32_t>(lane) >> 3;
     const uint2 ws = v.wstart[static_cast<uint64_t>(blk) * kBkWaves + w];
     const uint32_t T = ws.y;  // steps of this wave's stream, the same for every column tile
@@ -153,23 +171,31 @@ __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_block_kernel(BlockVi
 
     uint2 *win = reinterpret_cast<uint2 *>(lds + kBkLdsWin + w * (kBkWinSteps * kBkSlots * 8));
     uint32_t pw = 0, wpos = 0, wend = 0;  // window held in `nxt`, position and end (steps) inside the window in LDS
-    uint2 nxt[4];
+    constexpr int kWinLoads = kBkWinSteps * kBkSlots / 64;  // coalesced 512-byte loads per window
+    uint2 nxt[kWinLoads];
     typedef uint32_t v2u __attribute__((ext_vector_type(2)));
     auto prefetch = [&](uint32_t widx) {  // read once per tile: non-temporal, so the stream does not displace B rows in L2 / Infinity Cache
         const uint32_t s0 = widx * (kBkWinSteps * kBkSlots) + lane;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < kWinLoads; ++i) {
             const v2u r = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(rec + min(s0 + i * 64u, last_rec)));
             nxt[i] = make_uint2(r.x, r.y);
         }
     };
     if (T) prefetch(0);
     auto refill = [&]() {
+#ifdef FLEX_TRACE
+        const uint64_t r0_ = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
-        for (int i = 0; i < 4; ++i) win[i * 64 + lane] = nxt[i];
+        for (int i = 0; i < kWinLoads; ++i) win[i * 64 + lane] = nxt[i];
         wend = min(kBkWinSteps, T - pw * kBkWinSteps);
         wpos = 0;
         if (++pw < n_win) prefetch(pw);
+#ifdef FLEX_TRACE
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bk_ph[4] += __builtin_amdgcn_s_memtime() - r0_;
+#endif
     };
 
     // n steps of the stream into `acc`.  HOT: B rows from the panel buffer at LDS offset `base`; else from global memory.
@@ -204,7 +230,20 @@ __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_block_kernel(BlockVi
 #pragma unroll
                 for (int u = 0; u < U; ++u) fma4(acc, as_f32(r[u].y), b[u]);
             }
-            if (j < m) {  // 1 .. U-1 steps left: wave-uniform branches, nothing fetched that is not used
+            if constexpr (!HOT) {
+                if (j < m) {  // 1 .. U-1 steps left: one more full block on clamped records (a gather the row makes anyway) with value 0;
+                              // no second set of arrays, which is what lets U_COLD be 10 inside the 128-register budget
+                    uint2 r[U];
+                    float4 b[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) r[u] = wp[min(j + u, m - 1) * kBkSlots];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) b[u] = fetch(r[u].x);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) fma4(acc, j + u < m ? as_f32(r[u].y) : 0.f, b[u]);
+                }
+            } else if (j < m) {  // 1 .. U-1 steps left: wave-uniform branches, no LDS read that is not used (the panel phases are
+                                 // sensitive to every extra LDS read: clamped full blocks measured 7 % slower, U_HOT = 8 slower still)
                 const uint32_t rem = m - j;
                 uint2 r[U - 1];
                 float4 b[U - 1];
@@ -230,15 +269,20 @@ __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_block_kernel(BlockVi
         float4 acc[ROUNDS];
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        BK_STAMP(0);
         // cold phase: while the loader stages panel 0
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) run(std::false_type{}, acc[r], steps_of(r), lane_goff);
+        BK_STAMP(1);
         consumer_barrier();
+        BK_STAMP(3);
         for (uint32_t p = 0; p < np; ++p) {
             const uint32_t base = (p & 1) * kBkBufBytes + static_cast<uint32_t>(l8) * 16u;
 #pragma unroll
             for (int r = 0; r < ROUNDS; ++r) run(std::true_type{}, acc[r], steps_of((p + 1) * ROUNDS + r), base);
+            BK_STAMP(2);
             consumer_barrier();
+            BK_STAMP(3);
         }
         // a long row occupies 2 / 4 / 8 aligned slots: butterfly over the slots, then the first slot of each row stores.
         // A HUB row occupies whole groups on several waves: parts 1.. leave their sums in LDS (the panel buffers are free now),
@@ -296,6 +340,16 @@ __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_block_kernel(BlockVi
                 __builtin_nontemporal_store(val, reinterpret_cast<v4f *>(C + static_cast<uint64_t>(crow) * v.ldc + c0));
             }
         }
+#ifdef FLEX_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BK_STAMP(5);
+        bk_ph[6] = bk_last - bk_t0;
+        bk_ph[7] = T;
+        if (lane == 0 && v.trace != nullptr) {
+            uint64_t *o = v.trace + ((static_cast<uint64_t>(blockIdx.y) * v.n_blocks + blk) * kBkWaves + w) * 8;
+            for (int i = 0; i < 8; ++i) o[i] = bk_ph[i];
+        }
+#endif
     }
 }
 
@@ -304,8 +358,11 @@ int launch_rounds(const BlockView &bv, const float *dB, float *dC, hipStream_t s
     const uint32_t nblk = (bv.n_blocks + kXcds - 1) / kXcds * kXcds;
     // gathers in flight per wave in the cold phase: as many as the 128-register budget of a 1024-thread workgroup leaves
     // next to the accumulators (checked with -Rpass-analysis=kernel-resource-usage: no scratch)
-    constexpr int kUCold = ROUNDS <= 1 ? 8 : ROUNDS <= 4 ? 6 : 4;
-    hipLaunchKernelGGL((spmm_block_kernel<ROUNDS, 4, kUCold>), dim3(nblk, (bv.k + 31) / 32), dim3(64 * (kBkWaves + 1)), 0, s, bv, dB, dC);
+    constexpr int kUCold = ROUNDS <= 4 ? 10 : 8;
+#ifndef FLEX_BK_U_HOT  // experiment builds (make block_variants)
+#define FLEX_BK_U_HOT 4
+#endif
+    hipLaunchKernelGGL((spmm_block_kernel<ROUNDS, FLEX_BK_U_HOT, kUCold>), dim3(nblk, (bv.k + 31) / 32), dim3(64 * (kBkWaves + 1)), 0, s, bv, dB, dC);
     FLEX_HIP_TRY(hipGetLastError());
     return FLEX_OK;
 }

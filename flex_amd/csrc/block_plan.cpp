@@ -291,11 +291,42 @@ int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const st
                     o.cnt[static_cast<size_t>(w) * cw + idx / 2] |= steps << (16 * (idx & 1));
                     const size_t base = o.rec.size();
                     o.rec.resize(base + static_cast<size_t>(steps) * kBkSlots);
-                    for (uint32_t s = 0; s < kBkSlots; ++s) {
-                        const size_t sp = static_cast<size_t>(g * kBkSlots + s) * n_ph + ph;
-                        const uint32_t have = cnt_sp[sp];
-                        const uint2 pad = ph == 0 ? make_uint2(pad_off[g * kBkSlots + s], 0u) : make_uint2(kBkZeroRow, 0u);
-                        for (uint32_t q = 0; q < steps; ++q) o.rec[base + static_cast<size_t>(q) * kBkSlots + s] = q < have ? rec_sp[beg_sp[sp] + q] : pad;
+                    if (ph == 0) {
+                        for (uint32_t s = 0; s < kBkSlots; ++s) {
+                            const size_t sp = static_cast<size_t>(g * kBkSlots + s) * n_ph;
+                            const uint32_t have = cnt_sp[sp];
+                            const uint2 pad = make_uint2(pad_off[g * kBkSlots + s], 0u);
+                            for (uint32_t q = 0; q < steps; ++q) o.rec[base + static_cast<size_t>(q) * kBkSlots + s] = q < have ? rec_sp[beg_sp[sp] + q] : pad;
+                        }
+                    } else {
+                        // LDS banks.  One ds_read_b128 of the wave serves its 64 lanes in four groups of 16 (MI355X_MICROARCH.md, LDS);
+                        // with 8 lanes per slot a group holds a 64-byte half of FOUR slots' rows, and the halves of slots (0,3), (1,2),
+                        // (4,7), (5,6) land on the same 16 banks whenever the two panel rows have the same parity (a row is 128 bytes = 32
+                        // of the 64 banks): a 2-way conflict in half of the steps, measured as 7 instead of 4 cycles per instruction --
+                        // the panel phases ARE LDS-bound.  The order of a slot's records inside a (panel, round) group is free, so the
+                        // first slot of each pair takes its even rows first and the second its odd rows first; a padding record takes
+                        // the zero row of the parity its partner does not use.
+                        static const uint8_t kPartner[kBkSlots] = {3, 2, 1, 0, 7, 6, 5, 4};
+                        static const uint8_t kEvenFirst[kBkSlots] = {1, 1, 0, 0, 1, 1, 0, 0};
+                        std::vector<uint2> lst[kBkSlots];
+                        for (uint32_t s = 0; s < kBkSlots; ++s) {
+                            const size_t sp = static_cast<size_t>(g * kBkSlots + s) * n_ph + ph;
+                            lst[s].assign(rec_sp.begin() + beg_sp[sp], rec_sp.begin() + beg_sp[sp] + cnt_sp[sp]);
+                            const uint32_t want = kEvenFirst[s] ? 0u : 1u;  // parity of the rows that go first
+                            std::stable_partition(lst[s].begin(), lst[s].end(), [&](const uint2 &r) { return ((r.x / kBkRowBytes) & 1u) == want; });
+                        }
+                        for (uint32_t q = 0; q < steps; ++q)
+                            for (uint32_t s = 0; s < kBkSlots; ++s) {
+                                uint2 r;
+                                if (q < lst[s].size()) {
+                                    r = lst[s][q];
+                                } else {
+                                    const uint32_t t = kPartner[s];
+                                    const uint32_t partner_parity = q < lst[t].size() ? (lst[t][q].x / kBkRowBytes) & 1u : 1u;
+                                    r = make_uint2(kBkZeroRow + (partner_parity ? 0u : kBkRowBytes), 0u);  // zero rows at panel rows kBkPanelMax (even) and +1 (odd)
+                                }
+                                o.rec[base + static_cast<size_t>(q) * kBkSlots + s] = r;
+                            }
                     }
                     step_pos += steps;
                 }

@@ -55,14 +55,21 @@ constexpr int kBkWaves = 15;                              // consumer waves per 
 constexpr int kBkSlots = 8;                               // slots per wave (8 lanes x float4 = one 32-column tile of one row)
 constexpr int kBkRowsPerRound = kBkWaves * kBkSlots;      // 120 row slots per round
 constexpr int kBkMaxRounds = 8;
-constexpr uint32_t kBkPanelMax = 480;                     // B rows per LDS panel
+#ifndef FLEX_BK_PANEL_MAX  // experiments build variants (make -C flex_amd/csrc block_variants); the product has one value
+#define FLEX_BK_PANEL_MAX 480
+#endif
+#ifndef FLEX_BK_WIN_STEPS
+#define FLEX_BK_WIN_STEPS 32
+#endif
+constexpr uint32_t kBkPanelMax = FLEX_BK_PANEL_MAX;       // B rows per LDS panel
 constexpr uint32_t kBkRowBytes = 128;                     // one B row of one column tile
-constexpr uint32_t kBkZeroRow = kBkPanelMax * kBkRowBytes; // byte offset, inside a panel buffer, of a row of zeros (padding records point at it)
-constexpr uint32_t kBkBufBytes = kBkZeroRow + kBkRowBytes;
-constexpr uint32_t kBkWinSteps = 32;                      // record window per consumer wave: 32 steps x 8 slots x 8 bytes = 2 KiB
+constexpr uint32_t kBkZeroRow = kBkPanelMax * kBkRowBytes; // byte offset, inside a panel buffer, of TWO rows of zeros (an even and an odd panel row: padding records point at them)
+constexpr uint32_t kBkBufBytes = kBkZeroRow + 2 * kBkRowBytes;
+constexpr uint32_t kBkWinSteps = FLEX_BK_WIN_STEPS;       // record window per consumer wave: 32 steps x 8 slots x 8 bytes = 2 KiB
 constexpr uint32_t kBkLdsWin = 2 * kBkBufBytes;
 constexpr uint32_t kBkLdsHcol = kBkLdsWin + kBkWaves * kBkWinSteps * kBkSlots * 8;
 constexpr uint32_t kBkLdsBytes = kBkLdsHcol + 2 * kBkPanelMax * 4;  // 157 696 of the CU's 163 840
+static_assert(kBkLdsBytes <= 163840 && kBkPanelMax % 8 == 0 && kBkWinSteps % 8 == 0, "the block kernel's LDS image must fit one CU");
 constexpr uint32_t kBkEmptyRow = 0x1FFFFFFFu;             // brow entry of a slot that holds no row
 constexpr uint32_t kBkMaxCounts = 256;                    // (1 + panels) x rounds step counts per wave, two per lane-held word
 
@@ -79,6 +86,7 @@ struct BlockView {
     int32_t k, ldb, ldc;
     uint32_t xcd_remap;
     uint32_t ablate;         // timing-only (tools/probe_blocks.py; results are WRONG): 1 no panel DMA, 2 no panel-phase work, 4 no cold-phase work
+    uint64_t *trace;         // -DFLEX_TRACE builds only (tools/trace_blocks.py): 8 cycle counters per (tile, block, wave); else nullptr
 };
 
 constexpr uint32_t kPartialFlag = 0x80000000u;

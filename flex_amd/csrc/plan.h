@@ -102,7 +102,7 @@ inline PlanView plan_view(const flex_plan *p, bool fused, uint64_t *trace) {
 }
 inline BlockView block_view(const flex_plan *p) {
     return BlockView{p->d_bk_hdr, p->d_bk_wstart, p->d_bk_cnt, p->d_bk_hcol, p->d_bk_brow, p->d_bk_grp, p->d_bk_rec, p->bk_blocks, p->bk_rounds, p->bk_panel_rows,
-                     p->k, p->ldb, p->ldc, 1u, p->bk_ablate};
+                     p->k, p->ldb, p->ldc, 1u, p->bk_ablate, p->trace};
 }
 inline TileView tile_view(const flex_plan *p) { return TileView{p->d_tile_a, p->d_tile_boff, p->d_rt_ptr, p->d_rt_rows, p->n_row_tiles}; }
 // float4 path: k and both strides multiples of 4, both base addresses 16-byte aligned

@@ -284,7 +284,7 @@ int flex_plan_self_check(const flex_plan *p) try {
                         const uint2 r = brec[pos + q];
                         if (cold) {
                             if (r.x % row_bytes != 0 || r.x / row_bytes >= static_cast<uint64_t>(p->n)) return FLEX_ERR_FORMAT;
-                        } else if (r.x == kBkZeroRow) {
+                        } else if (r.x == kBkZeroRow || r.x == kBkZeroRow + kBkRowBytes) {
                             if (r.y != 0) return FLEX_ERR_FORMAT;
                         } else if (r.x % kBkRowBytes != 0 || r.x / kBkRowBytes >= P) {
                             return FLEX_ERR_FORMAT;

@@ -10,6 +10,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import flex_amd  # noqa: E402
+if os.environ.get("PROBE_LIB"):  # an experiment build of the library (make -C flex_amd/csrc block_variants)
+    from flex_amd import binding
+    binding._SO = os.path.join(os.path.dirname(binding._SO), os.environ["PROBE_LIB"])
 from tools._timing import timeit  # noqa: E402
 
 args = sys.argv[1:] or ["reddit", "128"]
