@@ -25,6 +25,7 @@ int detect_dense_tiles(const flex_csr *A, int32_t r0, int32_t m, const std::vect
     struct Found {
         uint32_t rt, ct;
         std::vector<float> a;  // 1024, operand order
+        uint32_t mask[32];     // bit j of word i: an entry at (row i, column j)
     };
     std::vector<std::vector<Found>> found(static_cast<size_t>(nblk));
     std::vector<int64_t> h0(static_cast<size_t>(nblk), 0), h1(h0), h2(h0), cells(h0), moved(h0);
@@ -60,7 +61,7 @@ int detect_dense_tiles(const flex_csr *A, int32_t r0, int32_t m, const std::vect
                     if (cnt * 4 >= 1024) h1[b] += cnt;
                     if (cnt * 2 >= 1024) h2[b] += cnt;
                     if (thr > 0 && cnt >= thr) {
-                        Found f{static_cast<uint32_t>(rt), static_cast<uint32_t>(key[z] >> 32), std::vector<float>(1024, 0.f)};
+                        Found f{static_cast<uint32_t>(rt), static_cast<uint32_t>(key[z] >> 32), std::vector<float>(1024, 0.f), {}};
                         uint8_t taken[32][32] = {};
                         for (size_t y = z; y < z1; ++y) {
                             const int i = static_cast<int>((key[y] >> 27) & 31);
@@ -69,6 +70,7 @@ int detect_dense_tiles(const flex_csr *A, int32_t r0, int32_t m, const std::vect
                             const int j = static_cast<int>((colpos.empty() ? c : colpos[c]) & 31);
                             if (taken[i][j]) continue;  // a duplicate (row, col) entry stays with the vector kernel
                             taken[i][j] = 1;
+                            f.mask[i] |= 1u << j;
                             const int kk = j >> 1, lane = i + 32 * (j & 1);
                             f.a[((kk >> 2) * 64 + lane) * 4 + (kk & 3)] = A->vals[e];
                             in_tile[e - e_base] = 1;
@@ -98,6 +100,7 @@ int detect_dense_tiles(const flex_csr *A, int32_t r0, int32_t m, const std::vect
         for (auto &blk : found)
             for (Found &f : blk) {
                 out.a.insert(out.a.end(), f.a.begin(), f.a.end());
+                out.mask.insert(out.mask.end(), f.mask, f.mask + 32);
                 f.a = std::vector<float>();
                 for (uint32_t j = 0; j < 32; ++j) {
                     uint32_t pos = f.ct * 32 + j;

@@ -39,6 +39,7 @@ struct PlanView {
 struct TileView {
     const float *a;            // [n_tiles][4][64][4] tile values in MFMA A-operand order: (q,lane,e) = A[lane&31][2(4q+e) + (lane>>5)]
     const uint32_t *boff;      // [n_tiles][32] B row of each tile column: byte offset (off32) or row id
+    const uint32_t *mask;      // [n_tiles][32] bit j of word i: the tile holds an entry at (row i, column j) -- an explicit zero counts, an absent one does not
     const uint32_t *rt_ptr;    // [n_row_tiles+1] tiles of each listed row tile, in column order
     const uint32_t *rt_rows;   // [n_row_tiles][32] C row of each row of the row tile, 0xFFFFFFFF = none
     uint32_t n_row_tiles;

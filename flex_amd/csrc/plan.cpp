@@ -62,6 +62,7 @@ void free_plan_device(flex_plan *p) {
     (void)hipFree(p->d_split_cnt);
     (void)hipFree(p->d_tile_a);
     (void)hipFree(p->d_tile_boff);
+    (void)hipFree(p->d_tile_mask);
     (void)hipFree(p->d_rt_ptr);
     (void)hipFree(p->d_rt_rows);
     (void)hipFree(p->d_bk_hdr);

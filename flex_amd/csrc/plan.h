@@ -37,7 +37,7 @@ struct flex_plan {
     bool two_d = false;  // rows cut by column panel (phases), not only by length
     // dense 32x32 tiles routed to the MFMA kernel (tile_kernels.hip)
     float *d_tile_a = nullptr;
-    uint32_t *d_tile_boff = nullptr, *d_rt_ptr = nullptr, *d_rt_rows = nullptr;
+    uint32_t *d_tile_boff = nullptr, *d_tile_mask = nullptr, *d_rt_ptr = nullptr, *d_rt_rows = nullptr;
     uint32_t n_tiles = 0, n_row_tiles = 0;
     int64_t tile_nnz = 0;
     int64_t tile_hist[3] = {0, 0, 0}, tile_cells = 0;  // detector report
@@ -104,7 +104,7 @@ inline BlockView block_view(const flex_plan *p) {
     return BlockView{p->d_bk_hdr, p->d_bk_wstart, p->d_bk_cnt, p->d_bk_hcol, p->d_bk_brow, p->d_bk_grp, p->d_bk_rec, p->bk_blocks, p->bk_rounds, p->bk_panel_rows,
                      p->k, p->ldb, p->ldc, 1u, p->bk_ablate, p->trace};
 }
-inline TileView tile_view(const flex_plan *p) { return TileView{p->d_tile_a, p->d_tile_boff, p->d_rt_ptr, p->d_rt_rows, p->n_row_tiles}; }
+inline TileView tile_view(const flex_plan *p) { return TileView{p->d_tile_a, p->d_tile_boff, p->d_tile_mask, p->d_rt_ptr, p->d_rt_rows, p->n_row_tiles}; }
 // float4 path: k and both strides multiples of 4, both base addresses 16-byte aligned
 inline bool operands_vec4(const flex_plan *p, const float *dB, const float *dC) {
     return (p->k % 4 == 0) && (p->ldb % 4 == 0) && (p->ldc % 4 == 0) &&
@@ -121,6 +121,7 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
 struct DenseTiles {
     std::vector<float> a;           // [T][4][64][4]
     std::vector<uint32_t> boff;     // [T][32]
+    std::vector<uint32_t> mask;     // [T][32] which (row, column) cells of the tile hold an entry
     std::vector<uint32_t> rt_ptr;   // [R+1]
     std::vector<uint32_t> rt_rows;  // [R][32]
     int64_t nnz = 0;                // entries moved into tiles

@@ -603,6 +603,7 @@ class PlanBuilder {
         if (p->n_tiles) {
             if ((rc = upload(&p->d_tile_a, tiles.a, &p->device_bytes))) return rc;
             if ((rc = upload(&p->d_tile_boff, tiles.boff, &p->device_bytes))) return rc;
+            if ((rc = upload(&p->d_tile_mask, tiles.mask, &p->device_bytes))) return rc;
             if ((rc = upload(&p->d_rt_ptr, tiles.rt_ptr, &p->device_bytes))) return rc;
             if ((rc = upload(&p->d_rt_rows, tiles.rt_rows, &p->device_bytes))) return rc;
         }

@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void spmm_tile_kernel(TileView tv, const float
     float bq[4][NT];
     load_b(boff_cur, 0, bq);
     for (uint32_t t = t0; t < t1; ++t) {
+        bool any_bad = false;  // a non-finite B value among this tile's operands (per lane)
         const uint32_t tn = min(t + 1, t1 - 1);  // the last tile prefetches itself: harmless, keeps every load unconditional
         const uint32_t boff_nxt = tv.boff[static_cast<uint64_t>(tn) * 32 + j];
         f32x4 a_nxt[4];
@@ -84,15 +85,44 @@ __global__ __launch_bounds__(256) void spmm_tile_kernel(TileView tv, const float
             float bn[4][NT];
             if (q < 3) load_b(boff_cur, q + 1, bn);
             else load_b(boff_nxt, 0, bn);
+            // A tile is stored dense: its absent cells are zeros of the A operand, and 0 x inf = NaN would reach rows that do not
+            // reference that B row (the vector kernel, the oracle and the reference never touch it).  Non-finite B values therefore
+            // enter the MFMA as 0; their exact contribution -- to the rows whose cell is present, explicit zeros included -- is added
+            // after the tile by the masked pass below.
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q][e], col_ok[nt] ? bq[e][nt] : 0.f, acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float bv = col_ok[nt] ? bq[e][nt] : 0.f;
+                    const bool bad = (__float_as_uint(bv) & 0x7F800000u) == 0x7F800000u;
+                    any_bad |= bad;
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q][e], bad ? 0.f : bv, acc[nt], 0, 0, 0);
+                }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bq[e][nt] = bn[e][nt];
+        }
+        if (__builtin_amdgcn_ballot_w64(any_bad) != 0) {  // wave-uniform, rare: the exact share of this tile's non-finite B values
+            const uint32_t mask_l = tv.mask[static_cast<uint64_t>(t) * 32 + j];  // lane j holds row j's cell mask
+            for (int kc = 0; kc < 32; ++kc) {
+                const uint32_t off = __shfl(boff_cur, kc);
+                const float *brow = OFF32 ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + off)
+                                          : B + static_cast<uint64_t>(off) * ldb;
+                // A[i][kc] sits at (q, lane, e) = (kc >> 3, i + 32 (kc & 1), (kc >> 1) & 3) of the operand-ordered block
+                const float *acol = tv.a + (static_cast<uint64_t>(t) * 4 + (kc >> 3)) * 256 + ((kc >> 1) & 3) + 128 * (kc & 1);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float bv = col_ok[nt] ? brow[col[nt]] : 0.f;
+                    const bool bad = (__float_as_uint(bv) & 0x7F800000u) == 0x7F800000u;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int i = (reg & 3) + 8 * (reg >> 2) + 4 * half;  // the C row this register holds
+                        const uint32_t mi = __shfl(mask_l, i);
+                        if (bad && ((mi >> kc) & 1u)) acc[nt][reg] = fmaf(acol[i * 4], bv, acc[nt][reg]);
+                    }
+                }
+            }
         }
         boff_cur = boff_nxt;
 #pragma unroll

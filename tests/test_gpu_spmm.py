@@ -951,3 +951,41 @@ def test_measured_per_cu_imbalance_report():
     # odd k has no stamped twin: refused, not faked
     with pytest.raises(flex_amd.FlexError):
         Plan(a, 7).measure_imbalance(dev(random_B(a.n, 7, 1)).data_ptr(), torch.empty((a.m, 7), device="cuda").data_ptr(), 0)
+
+
+@pytest.mark.parametrize("k", [128, 100, 32])
+def test_mfma_route_keeps_non_finite_values_where_they_belong(k):
+    """A routed tile is stored dense, so its absent cells are zeros of the MFMA's A operand: 0 x inf must NOT turn into a NaN
+    in a row that does not reference that B row (the vector kernel, the oracle and the reference never touch it).  Block-dense
+    input of fill 0.7 (30 % of every routed tile absent), n not a multiple of 32 (the last column tile hangs over the edge and
+    is padded with a clamped column), inf / NaN / -inf planted in B rows that sit inside dense blocks, in the overhanging
+    tile and among the noise columns; an explicit zero VALUE of A next to an inf must still give NaN, as in the oracle."""
+    n = 3210
+    a = block_dense_graph(n, 64, 0.7, 5, seed=13)
+    a.vals[a.rowPtr[70] + 3] = 0.0  # a stored zero: it references its column like any other entry
+    zero_col = int(a.col[a.rowPtr[70] + 3])
+    B = random_B(n, k, 6)
+    bad_rows = [5, 64 + 17, 1000, n - 1, n - 2, zero_col]
+    B[bad_rows[0], :] = np.inf
+    B[bad_rows[1], min(5, k - 1)] = np.nan
+    B[bad_rows[2], :: 7] = -np.inf
+    B[bad_rows[3], :] = np.inf
+    B[bad_rows[4], 0] = np.nan
+    B[zero_col, :] = np.inf
+    p = Plan(a, k, tuning={"mfma": 1, "mfma_fill_pct": 50})
+    info = p.info()
+    assert info["n_tiles"] > 150 and info["tile_nnz"] > 0.6 * a.nnz, info  # the route is taken
+    C = run_plan(p, B)
+    gold = oracle.spmm(a.rowPtr, a.col, a.vals, B)
+    assert np.array_equal(np.isfinite(C), np.isfinite(gold))
+    assert np.array_equal(np.isnan(gold[70]), np.isnan(C[70])) and np.isnan(gold[70]).any()  # the stored zero times inf
+    fin = np.isfinite(gold)
+    assert np.allclose(C[fin], gold[fin], rtol=1e-5, atol=1e-5)
+    # and the finite rows are bit-identical to what the same plan gives on a finite B (the masked pass only adds non-finite terms)
+    Bf = B.copy()
+    Bf[~np.isfinite(Bf)] = 0.25
+    rows_touched = np.zeros(n, bool)
+    rows = np.repeat(np.arange(n), np.diff(a.rowPtr.astype(np.int64)))
+    rows_touched[rows[np.isin(a.col, bad_rows)]] = True
+    Cf = run_plan(p, Bf)
+    assert np.array_equal(C[~rows_touched], Cf[~rows_touched])
