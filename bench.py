@@ -52,6 +52,10 @@ def parse():
     ap.add_argument("--no-vendor", action="store_true", help="skip the hipSPARSE side-by-side (N=1 only)")
     ap.add_argument("--check", action="store_true", help="verify rank 0's shard against the oracle (small workloads)")
     ap.add_argument("--shrink", type=int, default=1, help="rehearsals only: the preset with n and nnz divided by this (same generator and code path)")
+    ap.add_argument("--host-threads", type=int, default=0, help="worker threads of the planner / orderings / generator in THIS process "
+                                                               "(default: host cores / ranks on this node, at most 32)")
+    ap.add_argument("--perm-cache", default=None, help="file that holds the row ordering (rank[old] = new, keyed by a fingerprint of the matrix): "
+                                                       "loaded if it matches, else computed once (by rank 0) and written; saves the 2 s ordering of a re-run")
     ap.add_argument("--tuning", default="", help="plan-time knobs, fields of flex_plan_tuning: e.g. blocks=1,block_rounds=4 (experiments; default: the planner's rules)")
     ap.add_argument("--init-timeout", type=float, default=600.0, help="seconds to wait for the other ranks at start-up before failing (non-zero exit)")
     ap.add_argument("--dry-run", action="store_true",
@@ -82,6 +86,12 @@ def main():
         local_rank = int(os.environ["FLEX_BENCH_DEVICE"])
     if not args.dry_run:
         torch.cuda.set_device(local_rank)
+    # N ranks on one host plan at the same time: each gets its share of the cores (the planner would otherwise start up to 32
+    # threads per rank, 256 on an 8-GPU node)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    host_threads = args.host_threads or max(1, min(32, (os.cpu_count() or 1) // max(local_world, 1)))
+    flex_amd.set_host_threads(host_threads)
+    rccl_world = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
@@ -94,12 +104,14 @@ def main():
                 torch.cuda.synchronize()
                 if int(probe.item()) != world:
                     raise RuntimeError(f"all_reduce over {world} ranks returned {probe.item()}")
+                rccl_world = int(probe.item())  # what RCCL itself counted: goes into the JSON line
             else:
                 dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
                 probe = torch.ones(1)
                 dist.all_reduce(probe)
                 if int(probe.item()) != world:
                     raise RuntimeError(f"all_reduce over {world} ranks returned {probe.item()}")
+                rccl_world = 0  # a gloo rehearsal: RCCL was not involved
         except Exception as e:  # noqa: BLE001 -- a rank that cannot reach the others must fail the job, not hang it
             print(f"bench.py: rank {rank}: {args.backend} initialisation failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
             os._exit(3)  # no destructor may block on a half-made communicator; the launcher tears the other ranks down
@@ -135,14 +147,32 @@ def main():
              "natural": flex_amd.FLEX_ORDER_NATURAL}[args.order]
     want_stats = False
     tuning = {kv.split("=")[0].strip(): int(kv.split("=")[1]) for kv in args.tuning.split(",") if kv.strip()} or None
+    # the ordering: from the permutation cache when it matches this matrix; else computed ONCE (rank 0, then broadcast)
+    timings = {"order_s": 0.0}
+    rank_arr, cache_state = None, None
+    if args.perm_cache and args.order != "natural":
+        fp = flex_amd.csr_fingerprint(a)
+        try:
+            rank_arr, cache_state = flex_amd.perm_load(args.perm_cache, a.m, fp), "loaded"
+        except flex_amd.FlexError:
+            rank_arr = flex_amd.multigpu.shared_ordering(a, args.order, timings)
+            cache_state = "written"
+            if rank == 0:
+                flex_amd.perm_save(args.perm_cache, rank_arr, fp)
     if world == 1 and not args.dry_run:
         want_stats = a.nnz <= 50_000_000  # one extra pass over the records: skipped on amazon-size inputs
-        plan = flex_amd.Plan(a, k, device=local_rank, order=order | (flex_amd.FLEX_PLAN_STATS if want_stats else 0)
-                             | (flex_amd.FLEX_PLAN_AUTOTUNE if args.autotune else 0), tuning=tuning)
+        flags = (flex_amd.FLEX_PLAN_STATS if want_stats else 0) | (flex_amd.FLEX_PLAN_AUTOTUNE if args.autotune else 0)
+        if rank_arr is None:
+            plan = flex_amd.Plan(a, k, device=local_rank, order=order | flags, tuning=tuning)
+        else:  # the reference's flow: a reordered loader + vo_mp, planned in the order given
+            vo, ap = flex_amd.perm_csr(a, rank_arr)
+            plan = flex_amd.Plan(ap, k, device=local_rank, vo_mp=vo, tuning=tuning,
+                                 order=flags | (flex_amd.FLEX_PLAN_XCD_INTERLEAVE if args.order == "rcm" else 0))
+            del ap
         shard_nnz, shard_rows = a.nnz, a.m
         shard = None
     else:
-        shard = flex_amd.make_shard(a, k, rank, world, order=args.order)
+        shard = flex_amd.make_shard(a, k, rank, world, order=args.order, rank_arr=rank_arr, timings=timings if rank_arr is None else None)
         plan = None if args.dry_run else shard.plan(k, local_rank, tuning=tuning)
         shard_nnz, shard_rows = shard.nnz, shard.r1 - shard.r0
     t_plan = time.perf_counter() - t_plan
@@ -150,7 +180,7 @@ def main():
 
     # ---- B: generated on rank 0, broadcast once over RCCL/xGMI (untimed, reported)
     if args.dry_run:
-        return dry_run_tail(args, a, k, rank, world, shard, t_gen, t_plan)
+        return dry_run_tail(args, a, k, rank, world, shard, t_gen, t_plan, timings, host_threads, rccl_world, cache_state)
     dev = torch.device("cuda", local_rank)
     if rank == 0:
         g = torch.Generator(device=dev)
@@ -198,8 +228,8 @@ def main():
     per_rank = None
     if world > 1:
         # every rank's own figures (rank 0 reports them: which shard was the slow one), then the MAX over ranks
-        mine = torch.tensor([wall, dev_ms, float(shard_nnz), float(shard_rows)], device=dev if args.backend == "nccl" else "cpu",
-                            dtype=torch.float64)
+        mine = torch.tensor([wall, dev_ms, float(shard_nnz), float(shard_rows), t_plan, timings["order_s"]],
+                            device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [[float(x) for x in t_.tolist()] for t_ in allr]
@@ -242,7 +272,8 @@ def main():
                 "n": a.n, "nnz": a.nnz, "k": k, "order": args.order, "parallelism": f"row-shard x{world}",
                 "plan": {"chunks": info["n_chunks"], "tasks": info["n_tasks"], "split_rows": info["n_split_rows"],
                          "lanes_per_nz": info["lanes_per_nz"], "two_d": info["two_d"], "mfma_tiles": info["n_tiles"],
-                         "plan_s": round(t_plan, 3), "gen_s": round(t_gen, 3)},
+                         "blocks": info.get("n_blocks", 0), "plan_s": round(t_plan, 3), "order_s": round(timings["order_s"], 3),
+                         "gen_s": round(t_gen, 3), "host_threads": host_threads, "perm_cache": cache_state},
                 "b_bcast_ms": round(bcast_ms, 3),
                 # ≙ the README's "tPre/tElap" column (README.md:34-42): preprocessing (ordering + planning + upload) over
                 # one execution of the kernel
@@ -250,27 +281,37 @@ def main():
             },
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(args, world),
-                         "kernel": "spmm_flat_kernel", "kernel_ms": round(kern_ms, 6),
+                         "kernel": "spmm_block_kernel + spmm_flat_kernel" if info.get("n_blocks", 0) else "spmm_flat_kernel", "kernel_ms": round(kern_ms, 6),
                          "algorithmic_bytes_per_launch": int(b_alg),
-                         # the roof that binds high-degree graphs: every record pulls one B-row segment of
-                         # 16*G bytes through a CU's texture path, once per column tile, whether it hits the L2 or not;
-                         # MI355X_MICROARCH.md measures 16.8-18.8 TB/s chip-wide for L2-served row gathers
+                         # what the flat kernel asks of the texture path: every record pulls one B-row segment of 16*G
+                         # bytes, once per column tile, L2 hit or not.  NOT a roof: with every gather an L2 hit this kernel moves those
+                         # bytes at 22-23 TB/s (`all_l2_hit_ms_measured`, the folded-B probe), and the launch is then still slower
+                         # than its L2-miss traffic at the fabric's rate would make it -- both terms are reported, neither is claimed
                          "gather_demand_bytes_per_launch": int(gather_demand),
                          "gather_rate_GBps": round(gather_demand / (kern_ms * 1e-3) / 1e9, 1),
-                         "l2_gather_rate_measured_GBps": [16800, 18800]},
+                         "all_l2_hit_ms_measured": _all_hit_ms(args, world)},
         }
-        # the two terms of DESIGN.md 3.4's roof model for this launch: gather demand at the chip's measured L2 gather rate
-        # (18.6 TB/s, the upper half of the guide's 16.8-18.8) and -- when the committed PMC figure applies -- L2-miss traffic at the
-        # 6.3 TB/s the fabric delivers; the launch time is about the larger of the two
-        out["roofline"]["model_gather_floor_ms"] = round(gather_demand / 18.6e12 * 1e3, 6)
+        # the fabric term of DESIGN.md 3.4: the launch's L2-miss traffic (committed PMC figure, when it applies to the running
+        # sources) at the 6.3 TB/s the fabric delivers
         if out["roofline"]["traffic"] is not None:
             out["roofline"]["model_fabric_ms"] = round(out["roofline"]["traffic"] / 6.3e12 * 1e3, 6)
             # the north_star's "rocprof-measured HBM GB/s against the chip's peak": PMC bytes of the launch (memory side of
             # the L2s: HBM + Infinity Cache) over the launch time measured here; `frac` above is the ALGORITHMIC bytes' share
             out["roofline"]["traffic_GBps"] = round(out["roofline"]["traffic"] / (kern_ms * 1e-3) / 1e9, 1)
             out["roofline"]["traffic_frac_of_peak"] = round(out["roofline"]["traffic"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if world > 1:
+            out["config"]["rccl_world"] = rccl_world  # ranks RCCL's own all-reduce counted at start-up (0: gloo rehearsal)
         if per_rank is not None:
             nnzs = [r[2] for r in per_rank]
+            out["config"]["per_rank_plan_s"] = [round(r[4], 3) for r in per_rank]
+            out["config"]["per_rank_order_s"] = [round(r[5], 3) for r in per_rank]  # the ordering runs on rank 0 only (then broadcast)
+            # every rank's own roofline: its shard's algorithmic bytes (rowPtr + records + all of B + its C rows) over its launch time
+            prf = []
+            for r in per_rank:
+                b_r = 4.0 * (r[3] + 1) + 8.0 * r[2] + 4.0 * a.n * k + 4.0 * r[3] * k
+                gbps = b_r / (max(r[1], 1e-9) / args.steps * 1e-3) / 1e9
+                prf.append({"algorithmic_bytes": int(b_r), "achieved": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBS, 4)})
+            out["roofline"]["per_rank"] = prf
             out["config"]["per_rank_ms"] = [round(r[1] / args.steps, 6) for r in per_rank]        # HIP events, per step
             out["config"]["per_rank_wall_ms"] = [round(r[0] * 1e3 / args.steps, 6) for r in per_rank]
             out["config"]["per_rank_nnz"] = [int(x) for x in nnzs]
@@ -320,7 +361,7 @@ def main():
         dist.destroy_process_group()
 
 
-def dry_run_tail(args, a, k, rank, world, shard, t_gen, t_plan):
+def dry_run_tail(args, a, k, rank, world, shard, t_gen, t_plan, timings, host_threads, rccl_world, cache_state):
     """--dry-run: the host side of the N-rank path without a GPU -- B by one broadcast, every rank's shard reported to
     rank 0, which checks that the shards tile the rows and prints the JSON line (times zero: nothing was measured)."""
     import torch
@@ -332,7 +373,7 @@ def dry_run_tail(args, a, k, rank, world, shard, t_gen, t_plan):
         import flex_amd
         flex_amd.broadcast_dense(B, src=0, method=args.bcast)
     bcast_ms = (time.perf_counter() - t0) * 1e3
-    mine = (shard.r0, shard.r1, shard.nnz, float(B.double().sum()), [int(x) for x in shard.bounds])
+    mine = (shard.r0, shard.r1, shard.nnz, float(B.double().sum()), [int(x) for x in shard.bounds], t_plan, timings["order_s"], host_threads)
     allr = [None] * world
     if world > 1:
         dist.all_gather_object(allr, mine)
@@ -349,8 +390,11 @@ def dry_run_tail(args, a, k, rank, world, shard, t_gen, t_plan):
                "config": {"workload": f"{args.workload}-shape synthetic graph (n={a.n}, nnz={a.nnz}), k={k}, fp32, {args.order} schedule, "
                                       f"rows sharded over {world} ranks, B broadcast once (DRY RUN: no GPU, nothing measured)",
                           "n": a.n, "nnz": a.nnz, "k": k, "order": args.order, "parallelism": f"row-shard x{world}",
-                          "plan": {"plan_s": round(t_plan, 3), "gen_s": round(t_gen, 3)}, "b_bcast_ms": round(bcast_ms, 3),
+                          "plan": {"plan_s": round(t_plan, 3), "gen_s": round(t_gen, 3), "host_threads": host_threads, "perm_cache": cache_state},
+                          "b_bcast_ms": round(bcast_ms, 3), "rccl_world": rccl_world,
                           "per_rank_ms": [0.0] * world, "per_rank_nnz": nnzs, "per_rank_rows": [r[1] - r[0] for r in allr],
+                          "per_rank_plan_s": [round(r[5], 3) for r in allr], "per_rank_order_s": [round(r[6], 3) for r in allr],
+                          "per_rank_host_threads": [r[7] for r in allr],
                           "shard_nnz_imbalance_pct": round(100.0 * max(nnzs) * world / max(sum(nnzs), 1) - 100.0, 2)}}
         print(json.dumps(out), flush=True)
         if not ok:
@@ -375,6 +419,16 @@ def traffic_source_hash():
             if code:
                 h.update(code.encode() + b"\n")
     return h.hexdigest()[:16]
+
+
+def _all_hit_ms(args, world):
+    """The launch time of THIS kernel with every B gather an L2 hit -- measured (tools/probe_bound.py: same plan, the B row a
+    record names folded onto 1024 rows), committed as profiles/r03_all_l2_hit.json; null for a workload that was not probed."""
+    try:
+        e = json.load(open(os.path.join(ROOT, "profiles", "r03_all_l2_hit.json"))).get(f"{args.workload}_k{args.k}")
+        return None if e is None or world != 1 or args.order != "cluster" else round(e["us"] / 1e3, 6)
+    except Exception:
+        return None
 
 
 def _pmc_traffic(args, world):

@@ -69,7 +69,7 @@ int flex_plan_measure_imbalance(flex_plan *p, const float *dB, float *dC, flex_s
     if (!p || !out || !dC || (!dB && p->nnz > 0)) return FLEX_ERR_INVALID;
     *out = flex_imbalance{};
     if (p->m == 0 || p->n_slots == 0) return FLEX_OK;
-    if (!operands_vec4(p, dB, dC)) return FLEX_ERR_UNSUPPORTED;  // the stamped twin exists for the vector kernel only
+    if (!operands_vec4(p, dB, dC) || p->bk_blocks) return FLEX_ERR_UNSUPPORTED;  // the stamped twin exists for the vector kernel only (not for row blocks)
     int cur = -1;
     FLEX_HIP_TRY(hipGetDevice(&cur));
     if (cur != p->device) FLEX_HIP_TRY(hipSetDevice(p->device));

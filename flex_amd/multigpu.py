@@ -54,13 +54,53 @@ class RowShard:
         return rows if self.vo_mp is None else self.vo_mp[rows]
 
 
-def make_shard(a: "_b.HostCsr", k: int, rank: int, world: int, order: str = "cluster") -> RowShard:
+ORDERINGS = {"rcm": _b.order_rcm, "cluster": _b.order_cluster, "deg": _b.order_deg, "gorder": _b.order_gorder, "dfs": _b.order_dfs}
+
+
+def shared_ordering(a: "_b.HostCsr", order: str, timings: dict | None = None) -> np.ndarray:
+    """rank[old] = new for `a`, computed ONCE per job: with torch.distributed up, rank 0 runs the ordering (the community order
+    of the Amazon shape is 2 s on 32 threads and 4 GB of scratch) and broadcasts the 4n bytes; the other ranks only receive.
+    Without a process group (one process), computed here.  timings["order_s"] = seconds THIS rank spent ordering."""
+    import time
+    t0 = time.perf_counter()
+    spent = 0.0
+    try:
+        import torch
+        import torch.distributed as dist
+        group = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    except ImportError:
+        group = False
+    if not group:
+        rank_arr = ORDERINGS[order](a)
+        spent = time.perf_counter() - t0
+    else:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        if dist.get_rank() == 0:
+            rank_arr = ORDERINGS[order](a)
+            spent = time.perf_counter() - t0
+            buf = torch.from_numpy(rank_arr.astype(np.int32)).to(dev)
+        else:
+            buf = torch.empty(a.m, dtype=torch.int32, device=dev)
+        dist.broadcast(buf, src=0)
+        rank_arr = buf.cpu().numpy().astype(np.uint32)
+    if timings is not None:
+        timings["order_s"] = spent
+    return rank_arr
+
+
+def make_shard(a: "_b.HostCsr", k: int, rank: int, world: int, order: str = "cluster", rank_arr: np.ndarray | None = None,
+               timings: dict | None = None) -> RowShard:
     """Every rank calls this with the same `a`: reorder first (so a shard's columns form a band /
-    a set of communities), then cut contiguous row ranges of equal cost (flex_shard_rows)."""
+    a set of communities), then cut contiguous row ranges of equal cost (flex_shard_rows).
+    rank_arr: a precomputed rank[old] = new (a permutation cache, or shared_ordering); else the ordering is computed by rank 0
+    and broadcast when a process group is up (shared_ordering)."""
+    if timings is not None:
+        timings["order_s"] = 0.0
     if order == "natural":
         vo, ap = None, a
     else:
-        rank_arr = {"rcm": _b.order_rcm, "cluster": _b.order_cluster, "deg": _b.order_deg, "gorder": _b.order_gorder, "dfs": _b.order_dfs}[order](a)
+        if rank_arr is None:
+            rank_arr = shared_ordering(a, order, timings)
         vo, ap = _b.perm_csr(a, rank_arr)
     bounds = _b.shard_rows(ap, k, world)
     return RowShard(ap, vo, bounds, rank, world)

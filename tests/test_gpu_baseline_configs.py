@@ -159,9 +159,9 @@ def test_four_rank_rehearsal_of_the_strong_scaling_bench_on_one_card():
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   FLEX_BENCH_DEVICE="0", FLEX_HOST_THREADS="4", OMP_NUM_THREADS="1")
+                   FLEX_BENCH_DEVICE="0", OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--backend", "gloo",
-                                       "--workload", "amazon", "--shrink", "32", "--steps", "5", "--warmup", "2", "--check"],
+                                       "--workload", "amazon", "--shrink", "32", "--steps", "5", "--warmup", "2", "--check", "--host-threads", "4"],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=root))
     outs = [p.communicate(timeout=900) for p in procs]
     for p, (so, se) in zip(procs, outs):
@@ -173,6 +173,8 @@ def test_four_rank_rehearsal_of_the_strong_scaling_bench_on_one_card():
     assert j["n_gpus"] == 4 and j["scaling"] == "strong" and j["check"]["mismatches"] == 0 and j["value"] > 0
     assert len(c["per_rank_ms"]) == 4 and min(c["per_rank_ms"]) > 0 and sum(c["per_rank_nnz"]) == c["nnz"]
     assert c["shard_nnz_imbalance_pct"] < 25.0 and c["b_bcast_ms"] > 0
+    assert c["rccl_world"] == 0 and c["per_rank_order_s"][0] > 0 and all(t == 0 for t in c["per_rank_order_s"][1:])
+    assert len(j["roofline"]["per_rank"]) == 4 and all(r["algorithmic_bytes"] > 0 and r["frac"] > 0 for r in j["roofline"]["per_rank"])
 
 
 def test_cxx_multi_gpu_driver_fails_loudly_without_enough_devices():

@@ -153,7 +153,7 @@ def _launch_bench(world, extra, timeout=600, env_extra=None, ranks=None):
     procs = []
     for r in (range(world) if ranks is None else ranks):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", FLEX_HOST_THREADS="2", **(env_extra or {}))
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", **(env_extra or {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world)] + extra, env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT))
     outs = [p.communicate(timeout=timeout) for p in procs]
@@ -166,7 +166,8 @@ def test_eight_rank_dry_run_of_the_bench_on_a_scaled_down_amazon():
     receive the same B, and rank 0's JSON line must carry the per-rank fields."""
     import json
     pytest.importorskip("torch")
-    procs, outs = _launch_bench(8, ["--dry-run", "--workload", "amazon", "--shrink", "512", "--scaling", "strong", "--bcast", "scatter_allgather"])
+    procs, outs = _launch_bench(8, ["--dry-run", "--workload", "amazon", "--shrink", "512", "--scaling", "strong", "--bcast", "scatter_allgather",
+                                    "--host-threads", "2"])
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-2000:]
     lines = [ln for so, _ in outs for ln in so.splitlines() if ln.startswith("{")]
@@ -177,6 +178,32 @@ def test_eight_rank_dry_run_of_the_bench_on_a_scaled_down_amazon():
     assert len(c["per_rank_ms"]) == 8 and len(c["per_rank_nnz"]) == 8 and sum(c["per_rank_nnz"]) == c["nnz"]
     assert sum(c["per_rank_rows"]) == c["n"] and min(c["per_rank_rows"]) > 0
     assert c["shard_nnz_imbalance_pct"] < 25.0 and "amazon/512" in c["workload"]
+    # multi-GPU readiness (verdict r02, item 4): the ordering runs on rank 0 ONLY and is broadcast; every rank reports its planning
+    # time and its share of the host's threads; the line says how many ranks the collective library itself counted
+    assert len(c["per_rank_order_s"]) == 8 and c["per_rank_order_s"][0] > 0 and all(t == 0 for t in c["per_rank_order_s"][1:]), c["per_rank_order_s"]
+    assert len(c["per_rank_plan_s"]) == 8 and min(c["per_rank_plan_s"]) > 0
+    assert c["per_rank_host_threads"] == [2] * 8
+    assert c["rccl_world"] == 0  # gloo rehearsal: present, and says that RCCL was not involved
+
+
+def test_default_host_threads_are_the_ranks_share_of_the_cores_and_the_perm_cache_round_trips(tmp_path):
+    """Without --host-threads a rank takes cores / ranks-on-this-node threads (8 ranks x 32 planner threads on one host otherwise);
+    --perm-cache: the first run computes the ordering on rank 0 and writes it, the second loads it and nobody orders."""
+    import json
+    pytest.importorskip("torch")
+    cache = str(tmp_path / "amazon.perm")
+    want = max(1, min(32, (os.cpu_count() or 1) // 4))
+    for state in ("written", "loaded"):
+        procs, outs = _launch_bench(4, ["--dry-run", "--workload", "amazon", "--shrink", "1024", "--perm-cache", cache])
+        for p, (so, se) in zip(procs, outs):
+            assert p.returncode == 0, se[-2000:]
+        j = json.loads([ln for so, _ in outs for ln in so.splitlines() if ln.startswith("{")][0])
+        c = j["config"]
+        assert j["shards_consistent"] and c["plan"]["perm_cache"] == state and c["per_rank_host_threads"] == [want] * 4
+        if state == "written":
+            assert c["per_rank_order_s"][0] > 0 and all(t == 0 for t in c["per_rank_order_s"][1:]) and os.path.getsize(cache) > 0
+        else:
+            assert all(t == 0 for t in c["per_rank_order_s"])
 
 
 def test_a_rank_that_cannot_reach_the_others_exits_nonzero_instead_of_hanging():
