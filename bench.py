@@ -38,6 +38,10 @@ def parse():
     ap.add_argument("--workload", default="amazon", help="synthetic preset: flickr|reddit|amazon|yelp|ppi|pubmed")
     ap.add_argument("--graph", default=None, help="a real graph instead of a preset: .csv (the reference's format), .mtx or .bin "
                                                   "(e.g. tests/golden/pubmed.csv, the one data file the reference ships); strong scaling only")
+    ap.add_argument("--variant", default="preset", choices=["preset", "best", "worst"],
+                    help="where on the stand-in generator's range the synthetic graph sits: the preset (15 %% uniformly random edges), `best` "
+                         "(none: every edge inside a community or its ring) or `worst` (40 %%); same n, nnz and degree law.  The headline is the preset; "
+                         "the other two bracket what the numbers owe to the generator (DESIGN.md 3.4).  --workload rmat20: no communities at all")
     ap.add_argument("--k", type=int, default=128)
     ap.add_argument("--order", default="cluster", choices=["cluster", "rcm", "natural"])
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
@@ -137,6 +141,16 @@ def main():
                                      near_window=sp.near_window, shuffle=bool(args.shuffle), gcn_norm=bool(sp.gcn_norm),
                                      directed=bool(sp.directed), seed=sp.seed)
             args.workload += f"/{args.shrink}"
+        elif args.workload.startswith("rmat"):
+            a = rmat_graph(int(args.workload[4:] or 20))
+            args.workload = f"R-MAT scale {int(args.workload[4:] or 20)} (a/b/c = 0.57/0.19/0.19, symmetrised, relabelled)"
+        elif args.variant != "preset":
+            sp = flex_amd.synth_preset(args.workload, scale)
+            p_in = sp.p_in + (1.0 - sp.p_in - sp.p_near) if args.variant == "best" else max(0.0, 0.60 - sp.p_near)  # random share 0 / 0.40
+            a = flex_amd.synth_graph(n=sp.n, nnz=sp.nnz, alpha=sp.alpha, community=sp.community, p_in=p_in, p_near=sp.p_near,
+                                     near_window=sp.near_window, shuffle=bool(args.shuffle), gcn_norm=bool(sp.gcn_norm),
+                                     directed=bool(sp.directed), seed=sp.seed)
+            args.workload += f" [{args.variant}: {100 * (1 - p_in - sp.p_near):.0f} % random edges]"
         else:
             a = flex_amd.synth_graph(args.workload, scale=scale, shuffle=bool(args.shuffle))
     t_gen = time.perf_counter() - t_gen
@@ -361,6 +375,26 @@ def main():
         dist.destroy_process_group()
 
 
+def rmat_graph(scale, edge_factor=16, seed=1):
+    """A graph WITHOUT communities (what no schedule can help): R-MAT a/b/c = 0.57/0.19/0.19, symmetrised, self loops, vertices
+    relabelled at random; values U(-1,1).  scale 20: 1 048 576 vertices, ~32 M nonzeros."""
+    import flex_amd
+    rng = np.random.default_rng(seed)
+    n, m = 1 << scale, edge_factor << scale
+    r = np.zeros(m, np.int64)
+    c = np.zeros(m, np.int64)
+    for lvl in range(scale):
+        u = rng.random(m)
+        r |= (u >= 0.76).astype(np.int64) << lvl
+        c |= (((u >= 0.57) & (u < 0.76)) | (u >= 0.95)).astype(np.int64) << lvl
+    perm = rng.permutation(n)
+    key = np.unique(np.concatenate([perm[r] * n + perm[c], perm[c] * n + perm[r], np.arange(n) * (n + 1)]))
+    rr, cc = key // n, key % n
+    rp = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rr, minlength=n), out=rp[1:])
+    return flex_amd.HostCsr(rp.astype(np.uint32), cc.astype(np.uint32), rng.uniform(-1, 1, len(cc)).astype(np.float32), n=n)
+
+
 def dry_run_tail(args, a, k, rank, world, shard, t_gen, t_plan, timings, host_threads, rccl_world, cache_state):
     """--dry-run: the host side of the N-rank path without a GPU -- B by one broadcast, every rank's shard reported to
     rank 0, which checks that the shards tile the rows and prints the JSON line (times zero: nothing was measured)."""
@@ -404,7 +438,8 @@ def dry_run_tail(args, a, k, rank, world, shard, t_gen, t_plan, timings, host_th
         dist.destroy_process_group()
 
 
-TRAFFIC_SOURCES = ("spmm_kernels.hip", "plan.h", "plan.cpp", "plan_build.cpp", "dense_tiles.cpp", "internal.h", "cluster.cpp", "synth.cpp")
+TRAFFIC_SOURCES = ("spmm_kernels.hip", "plan.h", "plan.cpp", "plan_build.cpp", "dense_tiles.cpp", "internal.h", "cluster.cpp", "synth.cpp",
+                   "block_kernels.hip", "block_plan.cpp")
 
 
 def traffic_source_hash():

@@ -273,7 +273,10 @@ class PlanBuilder {
         long auto_budget = std::clamp<long>(static_cast<long>((G <= 8 ? 16.0 : 8.0) * avg_deg), lo_budget, G <= 8 ? 512 : 256);
         // small inputs: keep at least ~2048 chunks (two waves per SIMD) before growing them (wiki-Vote shape, k=32:
         // 5.5 us at 128-160 records per chunk, 6.3 at 200)
-        auto_budget = std::min(auto_budget, std::max<long>(lo_budget, static_cast<long>(A->rowPtr[r1] - A->rowPtr[r0]) / 2048));
+        // (round 3, pubmed.csv k=32 with no row split: 4.8 us at 48-64 records per chunk, 4.9 at 96, 5.1 at 128, 5.6 at 192 -- on the G = 8
+        //  tile a graph this small may go down to 64; k=128 is flat from 64 to 128: profiles/r03_small_graph_sweep.txt)
+        const long n_rec = static_cast<long>(A->rowPtr[r1] - A->rowPtr[r0]);
+        auto_budget = std::min(auto_budget, std::max<long>(G <= 8 ? 64 : lo_budget, n_rec / 2048));
         wave_nnz = static_cast<uint32_t>(pick(tn.chunk_records, auto_budget));
         row_cost = static_cast<uint32_t>(pick(tn.row_cost, 16));
         // Contiguous XCD slices (workgroup ids remapped) keep a community's rows on ONE private L2; they pay when the
@@ -306,7 +309,13 @@ class PlanBuilder {
         // rows > 192 records split, 40 us with rows > 96 split; reddit is flat from 256 to 512;
         // DESIGN.md 3.3).  Pieces stay in schedule order: moving them to the
         // front of the XCD slices helped flickr by 3 % and cost reddit 12 % (half its chunks are pieces).
-        long_row = static_cast<uint32_t>(pick(tn.long_row, wave_nnz));
+        // A graph that does not fill the chip (fewer chunks than half the resident wave slots) gains nothing from cutting a row that is
+        // only a few gather blocks long -- the launch ends with its slowest wave either way -- and every split row costs the second
+        // launch (spmm_fixup_kernel): such rows stay whole up to 12 blocks of U gathers.  pubmed.csv (6 rows beyond one budget):
+        // k=32 7.1 -> 4.8 us, k=128 9.2 -> 7.1 us (profiles/r03_small_graph_sweep.txt; 5.4 / 8.2 with the in-launch sum of round 2).
+        long whole_row = wave_nnz;
+        if (n_rec / std::max<long>(wave_nnz, 1) <= 4096) whole_row = std::max<long>(wave_nnz, std::min<long>(4L * wave_nnz, 12L * S * (G >= 32 ? 8 : 4)));
+        long_row = static_cast<uint32_t>(pick(tn.long_row, whole_row));
         piece_len = std::max<uint32_t>(S, static_cast<uint32_t>(pick(tn.piece_records, wave_nnz)) / S * S);
 
         // Column panels (the 2-D schedule; ≙ the column spans of csr2_DiagTiling's rounds 2-3, mat.cu:680-942, and

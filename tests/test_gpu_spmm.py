@@ -308,6 +308,37 @@ def test_vendor_baseline_matches_oracle():
     assert_matches_oracle(a, B, Cd.cpu().numpy())
 
 
+@pytest.mark.parametrize("k", [4, 16, 28])
+def test_in_launch_sum_with_partial_slots_that_share_a_cache_line(knobs, k):
+    """k < 32: the k-wide partial sums of DIFFERENT rows share one 128-byte line, so a reducer's sc1 loads can pull a line into
+    its XCD's L2 while a neighbouring row's pieces are still being written -- the case most sensitive to how the opt-in in-launch
+    hand-off (split_rows = 1) is served.  100 launches under uneven load: same bits, right answer; and the default two-launch
+    form gives the same bits."""
+    knobs.set(split_rows=1)
+    a = random_csr(5000, 5000, 6, seed=191, long_rows={r: 500 + 11 * (r % 83) for r in range(0, 5000, 2)}, empty_frac=0.05)
+    Bn = random_B(a.n, k, 93)
+    B = dev(Bn)
+    p = Plan(a, k)
+    assert p.info()["n_split_rows"] >= 2400 and p.tuning()["split_rows"] == 1
+    ref = p(B).clone()
+    torch.cuda.synchronize()
+    assert_matches_oracle(a, Bn, ref.cpu().numpy(), nthreads=8)
+    C = torch.empty_like(ref)
+    filler = torch.empty(64 << 20, device="cuda")
+    for it in range(100):
+        C.fill_(float("nan"))
+        if it % 3 == 0:
+            filler.add_(1.0)
+        p(B, out=C)
+        if it % 20 == 19 or it < 3:
+            torch.cuda.synchronize()
+            assert torch.equal(C, ref), f"launch {it}: result changed"
+    torch.cuda.synchronize()
+    assert torch.equal(C, ref)
+    knobs.set(split_rows=2)
+    assert torch.equal(Plan(a, k)(B), ref)
+
+
 @pytest.mark.parametrize("split_rows", [1, 2])
 def test_split_row_reduction_is_stable_under_repetition(knobs, split_rows):
     """split_rows = 1: split rows are summed inside the launch by the last piece to arrive (write-through partial sums,

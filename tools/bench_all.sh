@@ -14,3 +14,10 @@ done
 # BASELINE configs[2] names RCM-reordered rows for the Reddit shape: the same protocol with RCM as the schedule (the community
 # schedule above is what the engine picks by itself)
 timeout -k 10 600 python bench.py --workload reddit --k 128 --order rcm --steps 50 --warmup 5 --no-cpu-baseline --no-copy-probe >> $out 2>> ${out%.jsonl}.err || echo "{\"failed\": \"reddit 128 rcm\"}" >> $out
+# the range, not only the point: the Reddit and Amazon shapes at the generator's extremes -- no uniformly random edges
+# (`best`) and 40 % of them (`worst`) -- next to the preset lines above, and a graph with no communities at all (R-MAT scale 20)
+for cfg in "reddit best 50" "reddit worst 50" "amazon best 10" "amazon worst 10"; do
+  set -- $cfg
+  timeout -k 10 600 python bench.py --workload $1 --variant $2 --k 128 --steps $3 --warmup 5 --no-cpu-baseline --no-copy-probe >> $out 2>> ${out%.jsonl}.err || echo "{\"failed\": \"$cfg\"}" >> $out
+done
+timeout -k 10 600 python bench.py --workload rmat20 --k 128 --steps 30 --warmup 5 --no-cpu-baseline --no-copy-probe >> $out 2>> ${out%.jsonl}.err || echo "{\"failed\": \"rmat20\"}" >> $out

@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 out, workload, k, order = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
-rnd = os.environ.get("FLEX_ROUND", "r02")
+rnd = os.environ.get("FLEX_ROUND", "r03")
 summ = json.load(open(os.path.join(out, "summary.json")))
 main = max((n for n in summ if n.startswith("spmm_") and "FETCH_SIZE" in summ[n]), key=lambda n: summ[n].get("avg_us", 0) * summ[n].get("calls", 1))
 d = summ[main]

@@ -40,16 +40,43 @@ for name, d in res.items():
         d["fetch_MB_x2"] = 2 * d["FETCH_SIZE"] / 1e3
     if "WRITE_SIZE" in d:
         d["write_MB"] = d["WRITE_SIZE"] / 1e3
-# measured B reuse u (≙ flex.cu:5513-5528) when the bench line with n, nnz, k is in kt.log
+# roofline of every SpMM kernel of the launch from THIS directory alone (verdict r02 item 6): algorithmic bytes of the workload
+# (4(m+1) + 8 nnz + 4 n k + 4 m k, from the bench line in kt.log), the kernel's average duration from the kernel
+# trace, the HBM-side traffic from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE: the gfx950 correction of MI355X_MICROARCH.md)
+# and the measured B reuse u (≙ flex.cu:5513-5528).  With several kernels per step (row blocks + flat rest, fix-up, MFMA tiles)
+# the step's figures are in "step".
+HBM_PEAK = 8.0e12
 try:
     cfg = None
     for line in open(f"{out}/kt.log"):
         if line.startswith("{") and '"config"' in line:
             cfg = json.loads(line)["config"]
-    for name, d in res.items():
-        if cfg and "fetch_MB_x2" in d and name.startswith("spmm_"):
-            nnz, n, k = cfg["nnz"], cfg["n"], cfg["k"]
-            d["u_l2"] = 4.0 * nnz * k / max(1.0, d["fetch_MB_x2"] * 1e6 - 8.0 * nnz - 4.0 * (n + 1))
+    if cfg:
+        nnz, n, k = cfg["nnz"], cfg["n"], cfg["k"]
+        b_alg = 4.0 * (n + 1) + 8.0 * nnz + 8.0 * n * k
+        step = {"b_alg": int(b_alg), "us": 0.0, "traffic_bytes": 0.0}
+        calls = [d.get("calls", 0) for name, d in res.items() if name.startswith("spmm_")]
+        per_step = max(calls) if calls else 1
+        for name, d in res.items():
+            if not name.startswith("spmm_") or "avg_us" not in d:
+                continue
+            share = d.get("calls", per_step) / per_step  # the stamped twin of the imbalance report runs once per process
+            d["b_alg"] = int(b_alg)
+            d["frac"] = round(b_alg / (d["avg_us"] * 1e-6) / HBM_PEAK, 4)
+            if "fetch_MB_x2" in d and "write_MB" in d:
+                d["traffic_bytes"] = int((d["fetch_MB_x2"] + d["write_MB"]) * 1e6)
+                d["traffic_over_b_alg"] = round(d["traffic_bytes"] / b_alg, 2)
+                d["traffic_GBps"] = round(d["traffic_bytes"] / (d["avg_us"] * 1e-6) / 1e9, 1)
+                d["u_l2"] = round(4.0 * nnz * k / max(1.0, d["fetch_MB_x2"] * 1e6 - 8.0 * nnz - 4.0 * (n + 1)), 3)
+            if share > 0.5 and ", true>" not in name:  # kernels that run every step (not the once-per-process stamped twin)
+                step["us"] += d["avg_us"]
+                step["traffic_bytes"] += d.get("traffic_bytes", 0)
+        if step["us"] > 0:
+            step["frac"] = round(b_alg / (step["us"] * 1e-6) / HBM_PEAK, 4)
+            step["traffic_over_b_alg"] = round(step["traffic_bytes"] / b_alg, 2) if step["traffic_bytes"] else None
+            step["traffic_bytes"] = int(step["traffic_bytes"])
+            step["workload"] = cfg.get("workload")
+            res["step"] = step
 except (OSError, KeyError, ValueError):
     pass
 print(json.dumps(res, indent=1))
