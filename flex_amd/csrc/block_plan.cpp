@@ -49,6 +49,31 @@ struct BlockOut {
 
 }  // namespace
 
+double estimate_hot_share(const flex_csr *A, const std::vector<uint32_t> &sched, uint32_t rows, uint32_t thr, int64_t stride) {
+    const int64_t m = static_cast<int64_t>(sched.size());
+    const int64_t nb = (m + rows - 1) / rows, ns = (nb + stride - 1) / stride;
+    std::vector<int64_t> hot(static_cast<size_t>(ns), 0), all(static_cast<size_t>(ns), 0);
+    parallel_chunks(ns, [&](int64_t q) {
+        const int64_t b = q * stride;
+        std::vector<uint32_t> cols;
+        for (int64_t i = b * rows; i < std::min<int64_t>(m, (b + 1) * rows); ++i) {
+            const uint32_t r = sched[i];
+            cols.insert(cols.end(), A->col + A->rowPtr[r], A->col + A->rowPtr[r + 1]);
+        }
+        std::sort(cols.begin(), cols.end());
+        for (size_t z = 0; z < cols.size();) {
+            size_t z1 = z;
+            while (z1 < cols.size() && cols[z1] == cols[z]) ++z1;
+            if (z1 - z >= thr) hot[q] += static_cast<int64_t>(z1 - z);
+            z = z1;
+        }
+        all[q] = static_cast<int64_t>(cols.size());
+    });
+    int64_t h = 0, a = 0;
+    for (int64_t q = 0; q < ns; ++q) h += hot[q], a += all[q];
+    return a > 0 ? static_cast<double>(h) / static_cast<double>(a) : 0.0;
+}
+
 int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const std::vector<uint32_t> &colpos, const int32_t *col_map,
                  const int32_t *dst_map, int32_t r0, uint32_t row_bytes32, const BlockKnobs &kn, BlockImage &img, std::vector<uint32_t> &rest) {
     const int64_t m = static_cast<int64_t>(sched.size());

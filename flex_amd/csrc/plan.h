@@ -145,6 +145,9 @@ struct BlockImage {  // host copy of what BlockView points at
     uint32_t n_blocks = 0, rounds = 0, panel_rows = 0;
     int64_t rows = 0, nnz = 0, hot_nnz = 0, hot_cols = 0, panels = 0;
 };
+// What share of the nonzeros of rows sched[...] would be HOT (their column used by >= thr nonzeros of the same block of `rows`
+// schedule-consecutive rows), looked at in every `stride`-th block: the planner's cheap look before it commits to the block route.
+double estimate_hot_share(const flex_csr *A, const std::vector<uint32_t> &sched, uint32_t rows, uint32_t thr, int64_t stride);
 // Rows sched[0..) of A (a row's C row: dst_map, or r - r0) into blocks; `rest` receives the schedule positions that stay flat.
 int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const std::vector<uint32_t> &colpos, const int32_t *col_map,
                  const int32_t *dst_map, int32_t r0, uint32_t row_bytes32, const BlockKnobs &kn, BlockImage &img, std::vector<uint32_t> &rest);

@@ -711,6 +711,7 @@ static int build_with_blocks(flex_plan *p, const flex_csr *A, int32_t r0, int32_
         kn.panel_rows = static_cast<uint32_t>(tuning.block_panel_rows);
     }
     if (tuning.block_thr) kn.thr = static_cast<uint32_t>(tuning.block_thr);
+    else kn.thr = 3;  // measured: thr 3 is 1-2 % ahead of 2 on the amazon shapes (fewer panels, less padding), level on reddit
     const double avg = m > 0 ? static_cast<double>(A->rowPtr[r1] - A->rowPtr[r0]) / m : 0.0;
     // a slot may be about three average rows long before its row is spread over 2 / 4 / 8 slots (the wave that holds it is
     // evened out against the others by the planner's longest-processing-time deal)
@@ -774,12 +775,31 @@ static int build_with_blocks(flex_plan *p, const flex_csr *A, int32_t r0, int32_
 
 int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const int32_t *col_map, const int32_t *dst_map, unsigned flags,
                const flex_plan_tuning &tuning, std::vector<uint32_t> *sched_cache, int force_G) try {
-    // Row blocks: on request only (tuning.blocks = 1) until the rule is measured; they need the float4 path's shapes, 32-bit
-    // B offsets, and no forced tile width (autotune candidates stay flat).
+    // Row blocks need the float4 path's shapes, 32-bit B offsets, and no forced tile width (autotune candidates stay flat).
     const bool block_shapes = p->k % 4 == 0 && p->ldb % 4 == 0 && p->ldc % 4 == 0 &&
                               static_cast<uint64_t>(A->n) * static_cast<uint64_t>(p->ldb) * 4u <= (uint64_t(1) << 32);
-    if (tuning.blocks == 1 && block_shapes && force_G == 0 && r1 > r0 && tuning.mfma != 1 && tuning.two_d != 1)
-        return build_with_blocks(p, A, r0, r1, col_map, dst_map, flags, tuning, sched_cache);
+    const bool can_block = block_shapes && force_G == 0 && r1 > r0 && tuning.mfma != 1 && tuning.two_d != 1 && tuning.blocks != 2;
+    if (tuning.blocks == 1 && can_block) return build_with_blocks(p, A, r0, r1, col_map, dst_map, flags, tuning, sched_cache);
+    // The rule (tuning.blocks = 0), from what was measured on MI355X: the block kernel moves the same bytes over
+    // the fabric as the flat one, so it only pays where the flat kernel is NOT bound by its L2 misses -- a large share of the
+    // nonzeros sits in columns that a block of 480 rows uses three times or more -- and where there are enough blocks to keep 256
+    // CUs busy to the end (one workgroup per CU): amazon shape without uniformly random edges 7.65 -> 6.53 ms (hot share 0.77), its
+    // preset 8.24 -> 8.34 (0.62), reddit shapes 0.86x (564 blocks).  The look costs one sort of every 16th block's columns.
+    const int64_t nnz_in = static_cast<int64_t>(A->rowPtr[r1]) - A->rowPtr[r0];
+    if (tuning.blocks == 0 && can_block && static_cast<int64_t>(r1 - r0) >= 480 * 2048 && nnz_in >= 48ll * (r1 - r0)) {
+        std::vector<uint32_t> local_cache;
+        std::vector<uint32_t> *cache = sched_cache ? sched_cache : &local_cache;
+        std::vector<uint32_t> *sched = nullptr, *colpos = nullptr;
+        int rc;
+        {
+            PlanBuilder pre(p, A, r0, r1, col_map, dst_map, flags, tuning, cache, 0);
+            if ((rc = pre.schedule_only(&sched, &colpos))) return rc;
+        }
+        const double share = estimate_hot_share(A, *cache, 480, 3, 16);
+        if (plan_timing_enabled()) std::fprintf(stderr, "plan: hot share of 480-row blocks (thr 3, every 16th) %.3f\n", share);
+        if (share >= 0.72) return build_with_blocks(p, A, r0, r1, col_map, dst_map, flags, tuning, cache);
+        return PlanBuilder(p, A, r0, r1, col_map, dst_map, flags, tuning, cache, force_G).run();  // the schedule is computed once
+    }
     return PlanBuilder(p, A, r0, r1, col_map, dst_map, flags, tuning, sched_cache, force_G).run();
 } catch (const std::bad_alloc &) {  // any host allocation of any stage
     return FLEX_ERR_NOMEM;

@@ -146,7 +146,9 @@ typedef struct flex_plan_tuning {
     int32_t host_threads;    /* host threads of this call (rule: flex_set_host_threads, else the core count, at most 32) */
     flex_cluster_tuning cluster;
     /* the row-block path (LDS-staged B panels) */
-    int32_t blocks;           /* 1: rows go to row blocks (one workgroup per block, hot B rows staged in LDS), 2: never */
+    int32_t blocks;           /* 1: rows go to row blocks (one workgroup per block, hot B rows staged in LDS), 2: never (rule: on very
+                                 large inputs -- >= 983 040 rows of average degree >= 48 -- when a sampled look finds >= 72 % of the
+                                 nonzeros in columns that a block of 480 rows uses three times or more; needs 16-byte aligned operands) */
     int32_t block_rounds;     /* rows per slot: 1, 2, 4 or 8; a block is rounds x 120 row slots (4) */
     int32_t block_panel_rows; /* B rows per LDS panel: a multiple of 8, at most 480 (480) */
     int32_t block_thr;        /* a column is hot (staged) when at least this many nonzeros of the block use it (2) */

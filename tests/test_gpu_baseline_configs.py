@@ -186,3 +186,41 @@ def test_cxx_multi_gpu_driver_fails_loudly_without_enough_devices():
     out = subprocess.run([exe, golden, "32", "--no-vendor", "--gpus", str(n + 2)], capture_output=True, text=True, timeout=300)
     assert out.returncode != 0
     assert "flex_mg_create failed" in out.stdout and "rccl result" in out.stdout, out.stdout[-1500:] + out.stderr[-500:]
+
+
+def test_amazon_shape_without_random_edges_takes_the_row_block_route_by_rule():
+    """The planner's rule for the row-block route (LDS-staged B panels): on a very large, strongly clustered input -- the Amazon
+    shape with no uniformly random edges, bench.py --variant best -- a sampled look finds > 72 % of the nonzeros in hot columns
+    and the plan is built of row blocks; the preset (15 % random edges) stays flat.  The block result is compared with the flat
+    plan of the same matrix over ALL rows (resCheck) and with float64 sums of sampled rows (hubs included)."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 24 * (1 << 30):
+        pytest.skip("needs ~12 GiB of HBM")
+    sp = flex_amd.synth_preset("amazon")
+    a = flex_amd.synth_graph(n=sp.n, nnz=sp.nnz, alpha=sp.alpha, community=sp.community, p_in=1.0 - sp.p_near, p_near=sp.p_near,
+                             near_window=sp.near_window, shuffle=True, gcn_norm=bool(sp.gcn_norm), seed=sp.seed)
+    k = 128
+    B = random_B(a.n, k, 64)
+    Bd = dev(B)
+    vo, ap = flex_amd.perm_csr(a, flex_amd.order_cluster(a))  # one ordering for both plans
+    pb = Plan(ap, k, vo_mp=vo)
+    ib = pb.info()
+    assert ib["n_blocks"] > 3000 and ib["block_rows"] > 0.99 * a.m and ib["block_hot_nnz"] > 0.7 * a.nnz, ib
+    assert pb.tuning()["blocks"] == 1
+    pb.self_check()
+    Cb = run_plan(pb, Bd)
+    pb.destroy()
+    pf = Plan(ap, k, vo_mp=vo, tuning={"blocks": 2})
+    assert pf.info()["n_blocks"] == 0
+    Cf = run_plan(pf, Bd)
+    pf.destroy()
+    cnt, max_err, me_nnz, _ = oracle.rescheck(Cf, Cb, a.rowPtr)
+    assert cnt == 0, (cnt, max_err, me_nnz)
+    deg = np.diff(a.rowPtr.astype(np.int64))
+    rows = np.concatenate([np.argsort(deg)[-10:], np.random.default_rng(5).choice(a.m, 200, replace=False)])
+    fp64_rows_check(a, B, Cb, rows)
+    del ap
+    # the preset: same shape, 15 % uniformly random edges -> hot share 0.62 -> flat
+    a2 = flex_amd.synth_graph("amazon")
+    p2 = Plan(a2, k, order=FLEX_ORDER_CLUSTER)
+    assert p2.info()["n_blocks"] == 0 and p2.tuning()["blocks"] == 0

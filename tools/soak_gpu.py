@@ -36,6 +36,12 @@ KNOBS = {
     "FLEX_XCD_BALANCE": [None, None, "2"],
     "FLEX_LDS_EXTRA": [None, None, "16384"],
     "FLEX_HOST_THREADS": [None, "1", "3", "16"],
+    # the row-block path (LDS-staged B panels): on for a third of the cases, every shape of its image
+    "FLEX_BLOCKS": [None, None, "1"],
+    "FLEX_BLOCK_ROUNDS": [None, "1", "2", "4", "8"],
+    "FLEX_BLOCK_PANEL_ROWS": [None, "8", "64", "256", "480"],
+    "FLEX_BLOCK_THR": [None, "1", "2", "3", "6"],
+    "FLEX_BLOCK_CAP": [None, "8", "30", "200"],
 }
 
 
@@ -83,7 +89,7 @@ while time.time() < t_end:
     for name, choices in KNOBS.items():
         os.environ.pop(name, None)
         v = choices[int(rng.integers(0, len(choices)))]
-        if v is not None and rng.random() < 0.6:
+        if v is not None and (rng.random() < 0.6 or name == "FLEX_BLOCKS"):
             env[name] = v
     os.environ.update(env)
     m = int(rng.choice([1, 31, 64, 65, 300, 1500, 4000, 20000, 60000]))
