@@ -31,6 +31,9 @@ struct PlanView {
     uint32_t xcd_remap;      // 1: remap workgroup ids so each XCD walks one contiguous slice of the schedule
     uint32_t lds_extra;      // bytes of unused dynamic LDS per workgroup (occupancy throttle, tuning only)
     uint32_t rec_nt;         // 1: the record stream is read with non-temporal loads
+    uint32_t tile_group;     // 0: column tiles are the slow grid dimension (one pass over all chunks per tile).  Else: workgroups per group --
+                             // every XCD slice of the chunk table is walked group by group, all column tiles of a group back to back, so that
+                             // a group's records are re-read while they are still in the Infinity Cache (1-D grid of n_workgroups x tiles)
     uint64_t *trace;         // flex_plan_measure_imbalance: 3 words per (k-tile, chunk-table entry); diagnostic -DFLEX_TRACE builds: 12 per wave; else nullptr
 };
 

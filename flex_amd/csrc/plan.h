@@ -23,6 +23,7 @@ struct flex_plan {
     bool xcd_remap = true;
     unsigned lds_extra = 0;
     bool rec_nt = false;
+    uint32_t tile_group = 0;
     int unroll = 0;
     uint64_t *trace = nullptr;
     unsigned order = 0;
@@ -98,7 +99,7 @@ void free_plan_device(flex_plan *p);
 inline PlanView plan_view(const flex_plan *p, bool fused, uint64_t *trace) {
     return PlanView{p->d_rec, p->d_t_beg, p->d_t_dst, p->d_t_aux, p->d_chunk, p->d_partial, p->d_split, p->d_split_cnt,
                     fused ? 1u : 0u, p->n_slots, p->k, p->ldb, p->ldc,
-                    p->xcd_remap ? 1u : 0u, p->lds_extra, p->rec_nt ? 1u : 0u, trace};
+                    p->xcd_remap ? 1u : 0u, p->lds_extra, p->rec_nt ? 1u : 0u, p->tile_group, trace};
 }
 inline BlockView block_view(const flex_plan *p) {
     return BlockView{p->d_bk_hdr, p->d_bk_wstart, p->d_bk_cnt, p->d_bk_hcol, p->d_bk_brow, p->d_bk_grp, p->d_bk_rec, p->bk_blocks, p->bk_rounds, p->bk_panel_rows,

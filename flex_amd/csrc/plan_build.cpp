@@ -301,7 +301,10 @@ class PlanBuilder {
         const long nt_env = tn.rec_nt;
         const int ktiles = (k + 4 * G - 1) / (4 * G);
         const uint64_t stream_bytes = static_cast<uint64_t>(A->rowPtr[r1] - A->rowPtr[r0]) * 8u;
-        p->rec_nt = nt_env == 1 || (nt_env != 2 && stream_bytes >= (ktiles >= 2 ? (32ull << 20) : (1ull << 30)));
+        // grouped tile order (tuning.tile_group; the rule is "off" until measured): the records of a group are meant to come back from
+        // the Infinity Cache on the group's later tiles, so they are read with ordinary loads there
+        p->tile_group = (ktiles >= 2 && tn.tile_group > 1) ? static_cast<uint32_t>(tn.tile_group) : 0u;
+        p->rec_nt = nt_env == 1 || (nt_env != 2 && p->tile_group == 0 && stream_bytes >= (ktiles >= 2 ? (32ull << 20) : (1ull << 30)));
         p->unroll = tn.unroll == 8 ? 8 : 0;
         // Rows longer than one budget are cut into pieces of one budget, each a chunk of its own that
         // writes a k-wide partial sum: one wave keeps only U gathers in flight, so a long row is much
@@ -343,6 +346,7 @@ class PlanBuilder {
         u.row_cost = static_cast<int32_t>(row_cost);
         u.xcd_slices = p->xcd_remap ? 1 : 2;
         u.rec_nt = p->rec_nt ? 1 : 2;
+        u.tile_group = p->tile_group ? static_cast<int32_t>(p->tile_group) : 1;
         u.unroll = p->unroll;
         u.two_d = two_d ? 1 : 0;
         u.panel_kb = static_cast<int32_t>(panel_bytes >> 10);

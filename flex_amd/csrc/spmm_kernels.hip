@@ -273,7 +273,7 @@ __device__ __forceinline__ void stage_window(uint2 *my_lds, const uint2 *__restr
 template <int G, bool OFF32, int U>
 __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint32_t my_beg, uint32_t my_dst, uint2 my_aux,
                                               uint2 *my_lds, const char *__restrict__ Bb,
-                                              float *__restrict__ C, int lane, int c0, bool col_ok
+                                              float *__restrict__ C, int lane, int c0, bool col_ok, uint32_t tile, uint32_t ktiles
 #ifdef FLEX_TRACE
                                               , uint64_t *phase, uint64_t &last_
 #endif
@@ -421,7 +421,7 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint32_t arrived = 0;
         if (mine_partial)
-            arrived = __hip_atomic_fetch_add(p.split_cnt + static_cast<uint64_t>(my_aux.x) * gridDim.y + blockIdx.y, 1u,
+            arrived = __hip_atomic_fetch_add(p.split_cnt + static_cast<uint64_t>(my_aux.x) * ktiles + tile, 1u,
                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint64_t done = __builtin_amdgcn_ballot_w64(mine_partial && arrived + 1 == my_aux.y);
         while (done != 0) {  // wave-uniform: up to S completed rows per round, slot s takes the s-th
@@ -459,7 +459,7 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
                     __builtin_nontemporal_store(val, reinterpret_cast<v4f *>(C + static_cast<uint64_t>(sr.row) * ldc + c0));
                 }
                 if (lane % G == 0)
-                    __hip_atomic_store(p.split_cnt + static_cast<uint64_t>(sidx) * gridDim.y + blockIdx.y, 0u, __ATOMIC_RELAXED,
+                    __hip_atomic_store(p.split_cnt + static_cast<uint64_t>(sidx) * ktiles + tile, 0u, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -485,14 +485,31 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(OFF32 
     __shared__ uint2 lds_rec[WPB][kWindowRecs<G>];
     const int lane = threadIdx.x & 63;
     const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t cpx = gridDim.x / kXcds;  // gridDim.x % 8 == 0
-    const uint32_t bid = p.xcd_remap ? (blockIdx.x % kXcds) * cpx + (blockIdx.x / kXcds) : blockIdx.x;
+    // Which (workgroup of the chunk table, column tile) this workgroup is.  Classic: blockIdx.y = tile, one pass over the whole
+    // table per tile.  Grouped (p.tile_group): a 1-D grid in which every XCD slice is walked group by group, the tiles of a group
+    // back to back -- a group's records are then re-read from the Infinity Cache instead of HBM.
+    uint32_t tile = blockIdx.y, ktiles = gridDim.y, bid;
+    if (p.tile_group == 0) {
+        const uint32_t cpx = gridDim.x / kXcds;  // gridDim.x % 8 == 0
+        bid = p.xcd_remap ? (blockIdx.x % kXcds) * cpx + (blockIdx.x / kXcds) : blockIdx.x;
+    } else {
+        ktiles = (p.k + 4 * G - 1) / (4 * G);
+        const uint32_t nwg = gridDim.x / ktiles;                        // workgroups of one pass (a multiple of 8)
+        const uint32_t slice = p.xcd_remap ? nwg / kXcds : nwg;         // ... of one XCD's slice
+        const uint32_t l = p.xcd_remap ? blockIdx.x / kXcds : blockIdx.x;  // position in this XCD's extended slice [0, slice * ktiles)
+        const uint32_t g = l / (p.tile_group * ktiles), r = l % (p.tile_group * ktiles);
+        const uint32_t g0 = g * p.tile_group, gs = min(p.tile_group, slice - g0);  // the last group of a slice may be short
+        tile = r / gs;
+        const uint32_t in_slice = g0 + r % gs;
+        if (tile >= ktiles) return;  // only past the end of a short last group
+        bid = p.xcd_remap ? (blockIdx.x % kXcds) * slice + in_slice : in_slice;
+    }
     const uint32_t chunk = bid * WPB + wib;
     if (chunk >= p.n_chunks) return;
 #ifdef FLEX_ABL_EMPTY  // timing-only ablation: dispatch + one header load per wave, nothing else
     if (p.chunk[chunk].y != 0xFFFFFFFFu) return;
 #endif
-    const int c0 = blockIdx.y * (4 * G) + (lane % G) * 4;  // first of this lane's 4 columns
+    const int c0 = tile * (4 * G) + (lane % G) * 4;  // first of this lane's 4 columns
     const bool col_ok = c0 < p.k;                            // k % 4 == 0 on this path
 #ifdef FLEX_TRACE  // diagnostic build only (tools/trace.py)
     const uint64_t trace_t0 = __builtin_amdgcn_s_memrealtime();
@@ -502,7 +519,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(OFF32 
     const uint32_t my_beg = (static_cast<uint32_t>(lane) <= hdr.y) ? p.t_beg[hdr.x + lane] : 0u;
     const uint32_t my_dst = (static_cast<uint32_t>(lane) < hdr.y) ? p.t_dst[hdr.x + lane] : 0u;
     const uint2 my_aux = (static_cast<uint32_t>(lane) < hdr.y) ? p.t_aux[hdr.x + lane] : make_uint2(0u, 0u);
-    compute_chunk<G, OFF32, U>(p, hdr, my_beg, my_dst, my_aux, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok, phase, last_);
+    compute_chunk<G, OFF32, U>(p, hdr, my_beg, my_dst, my_aux, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok, tile, ktiles, phase, last_);
     if (lane == 0 && p.trace != nullptr) {
         uint64_t *log = p.trace + static_cast<uint64_t>(chunk) * 12;
         log[0] = xcc_id();
@@ -527,14 +544,14 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(OFF32 
     const uint2 my_aux = (static_cast<uint32_t>(lane) < hdr.y) ? p.t_aux[hdr.x + lane] : make_uint2(0u, 0u);  // read at chunk end only
     uint64_t stamp_t0 = 0;
     if constexpr (STAMP) stamp_t0 = __builtin_amdgcn_s_memrealtime();
-    compute_chunk<G, OFF32, U>(p, hdr, my_beg, my_dst, my_aux, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok);
+    compute_chunk<G, OFF32, U>(p, hdr, my_beg, my_dst, my_aux, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok, tile, ktiles);
     if constexpr (STAMP) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the wave's last stores have left
         const uint64_t stamp_t1 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0 && p.trace != nullptr) {
             uint32_t hw_id;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-            uint64_t *log = p.trace + (static_cast<uint64_t>(blockIdx.y) * p.n_chunks + chunk) * 3;
+            uint64_t *log = p.trace + (static_cast<uint64_t>(tile) * p.n_chunks + chunk) * 3;
             log[0] = stamp_t0;
             log[1] = stamp_t1;
             log[2] = (static_cast<uint64_t>(xcc_id()) << 32) | hw_id;
@@ -641,8 +658,8 @@ int launch_v4(const PlanView &v, const float *dB, float *dC, hipStream_t s) {
     uint32_t nblk = (v.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
     nblk = (nblk + kXcds - 1) / kXcds * kXcds;
     const uint32_t ktiles = (v.k + 4 * G - 1) / (4 * G);
-    hipLaunchKernelGGL((spmm_flat_kernel<G, OFF32, U, kWavesPerBlock>), dim3(nblk, ktiles), dim3(64 * kWavesPerBlock),
-                       v.lds_extra, s, v, dB, dC);
+    const dim3 grid = v.tile_group ? dim3(nblk * ktiles, 1) : dim3(nblk, ktiles);
+    hipLaunchKernelGGL((spmm_flat_kernel<G, OFF32, U, kWavesPerBlock>), grid, dim3(64 * kWavesPerBlock), v.lds_extra, s, v, dB, dC);
     FLEX_HIP_TRY(hipGetLastError());
     return FLEX_OK;
 }
@@ -652,10 +669,11 @@ int launch_stamped(const PlanView &v, bool off32, const float *dB, float *dC, hi
     uint32_t nblk = (v.n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
     nblk = (nblk + kXcds - 1) / kXcds * kXcds;
     const uint32_t ktiles = (v.k + 4 * G - 1) / (4 * G);
+    const dim3 grid = v.tile_group ? dim3(nblk * ktiles, 1) : dim3(nblk, ktiles);
     if (off32)
-        hipLaunchKernelGGL((spmm_flat_kernel<G, true, U, kWavesPerBlock, true>), dim3(nblk, ktiles), dim3(64 * kWavesPerBlock), v.lds_extra, s, v, dB, dC);
+        hipLaunchKernelGGL((spmm_flat_kernel<G, true, U, kWavesPerBlock, true>), grid, dim3(64 * kWavesPerBlock), v.lds_extra, s, v, dB, dC);
     else
-        hipLaunchKernelGGL((spmm_flat_kernel<G, false, U, kWavesPerBlock, true>), dim3(nblk, ktiles), dim3(64 * kWavesPerBlock), v.lds_extra, s, v, dB, dC);
+        hipLaunchKernelGGL((spmm_flat_kernel<G, false, U, kWavesPerBlock, true>), grid, dim3(64 * kWavesPerBlock), v.lds_extra, s, v, dB, dC);
     FLEX_HIP_TRY(hipGetLastError());
     return FLEX_OK;
 }

@@ -154,7 +154,10 @@ typedef struct flex_plan_tuning {
     int32_t block_thr;        /* a column is hot (staged) when at least this many nonzeros of the block use it (2) */
     int32_t block_cap;        /* records per slot beyond which a row takes 2 / 4 / 8 slots; rows beyond 8 x cap stay flat */
     int32_t block_ablate;     /* timing-only experiments, the RESULT IS WRONG: 1 no panel staging, 2 no panel-phase work, 4 no cold-phase work */
-    int32_t reserved[10];    /* zero */
+    int32_t tile_group;       /* multi-tile launches: workgroups per group -- every XCD's slice of the schedule is walked group by group, all
+                                 column tiles of a group back to back, so that a group's records are re-read from the Infinity Cache rather
+                                 than from HBM (0 = rule; 1 = off: one pass over the whole schedule per tile) */
+    int32_t reserved[9];     /* zero */
 } flex_plan_tuning;
 
 typedef struct flex_plan_desc {
