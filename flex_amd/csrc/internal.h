@@ -55,7 +55,10 @@ struct TileView {
 // them with ds_read_b128; the block's other nonzeros (COLD) gather from global memory as the flat kernel does.  A slot walks ONE
 // row (or one part of a long row) through all phases with its sum in registers, so C is written once and nothing is combined
 // across workgroups.
-constexpr int kBkWaves = 15;                              // consumer waves per workgroup
+#ifndef FLEX_BK_WAVES
+#define FLEX_BK_WAVES 15
+#endif
+constexpr int kBkWaves = FLEX_BK_WAVES;                   // consumer waves per workgroup
 constexpr int kBkSlots = 8;                               // slots per wave (8 lanes x float4 = one 32-column tile of one row)
 constexpr int kBkRowsPerRound = kBkWaves * kBkSlots;      // 120 row slots per round
 constexpr int kBkMaxRounds = 8;

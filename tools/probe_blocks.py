@@ -33,7 +33,7 @@ for name, k in zip(args[0::2], (int(x) for x in args[1::2])):
     B = torch.rand((ap.n, k), device="cuda") * 2 - 1
     C = torch.empty((ap.m, k), device="cuda")
     reps = 10 if ap.nnz > 1e8 else 30
-    p = flex_amd.Plan(ap, k, vo_mp=vo)
+    p = flex_amd.Plan(ap, k, vo_mp=vo, tuning={"blocks": 2})  # the flat kernel, whatever the planner's rule would pick
     t_flat = timeit(p, B, C, reps)
     ref = C.clone()
     p.destroy()

@@ -15,8 +15,13 @@ int main() {
     if (flex_synth_graph(&p, &a)) return 2;
     flex_csr v{a.m, a.n, a.nnz, a.rowPtr, a.col, a.vals};
     std::vector<uint32_t> r1(a.m), r2(a.m);
+    flex_set_host_threads(6);
     if (flex_order_cluster(&v, r1.data()) || flex_order_cluster(&v, r2.data())) return 3;
     if (r1 != r2) return 4;
+    // the new FirstError path of host_parallel.h under the race detector too: a per-call thread count inside a process-wide cap
+    flex_cluster_tuning ct{};
+    ct.batch = 1024;
+    if (flex_order_cluster_ex(&v, &ct, r2.data())) return 5;
     std::printf("tsan pass: generator + cluster ordering ok, n=%d\n", a.m);
     flex_host_csr_free(&a);
     return 0;
@@ -38,4 +43,4 @@ CPP
 g++ -std=c++20 -O1 -g -fsanitize=thread -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iflex_amd/csrc -o $out/t $out/main.cpp \
     flex_amd/csrc/plan.cpp flex_amd/csrc/plan_build.cpp flex_amd/csrc/block_plan.cpp flex_amd/csrc/plan_check.cpp flex_amd/csrc/dense_tiles.cpp flex_amd/csrc/ingest.cpp flex_amd/csrc/reorder.cpp flex_amd/csrc/cluster.cpp flex_amd/csrc/rabbit.cpp \
     flex_amd/csrc/gorder.cpp flex_amd/csrc/shard.cpp flex_amd/csrc/synth.cpp $out/shim.cpp -lpthread -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
-FLEX_HOST_THREADS=${FLEX_HOST_THREADS:-6} $out/t
+$out/t
