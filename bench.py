@@ -336,7 +336,9 @@ def main():
             out["config"]["plan"].update({
                 "b_reuse_wave": round(st["reuse_wave"], 3), "b_reuse_xcd": round(st["reuse_xcd"], 3),
                 "chunk_imb_pct": round(st["chunk_imb_pct"], 1), "xcd_imb_pct": round(st["xcd_imb_pct"], 2),
-                "split_nnz_pct": round(st["split_nnz_pct"], 2), "pad_pct": round(st["pad_pct"], 2)})
+                "split_nnz_pct": round(st["split_nnz_pct"], 2), "pad_pct": round(st["pad_pct"], 2),
+                # reuse a workgroup could have above the L2: share of nnz in columns a block of 480 rows uses >= 2 / 4 times, and u
+                "lds_hot_pct": [round(st["lds_hot_pct_2"], 1), round(st["lds_hot_pct_4"], 1)], "lds_u": [round(st["lds_u_2"], 2), round(st["lds_u_4"], 2)]})
             # bytes the launch must move if every XCD (private L2) fetches each B row it needs exactly once:
             # the floor of a row-partitioned schedule on this chip, between `algorithmic_bytes_per_launch` and `traffic`
             out["roofline"]["private_l2_model_bytes"] = int(st["l2_bytes"])

@@ -65,7 +65,8 @@ class _PlanStats(C.Structure):  # flex_plan_stats
                 ("chunk_imb_pct", C.c_double), ("xcd_imb_pct", C.c_double),
                 ("split_nnz_pct", C.c_double), ("pad_pct", C.c_double), ("n_workgroups", C.c_int64),
                 ("tile_nnz_pct_10", C.c_double), ("tile_nnz_pct_25", C.c_double), ("tile_nnz_pct_50", C.c_double),
-                ("tile_mean_fill", C.c_double), ("mfma_tiles", C.c_int64), ("mfma_nnz_pct", C.c_double)]
+                ("tile_mean_fill", C.c_double), ("mfma_tiles", C.c_int64), ("mfma_nnz_pct", C.c_double),
+                ("lds_hot_pct_2", C.c_double), ("lds_hot_pct_4", C.c_double), ("lds_u_2", C.c_double), ("lds_u_4", C.c_double)]
 
 
 class _ClusterTuning(C.Structure):  # flex_cluster_tuning

@@ -49,10 +49,10 @@ struct BlockOut {
 
 }  // namespace
 
-double estimate_hot_share(const flex_csr *A, const std::vector<uint32_t> &sched, uint32_t rows, uint32_t thr, int64_t stride) {
+double estimate_hot_share(const flex_csr *A, const std::vector<uint32_t> &sched, uint32_t rows, uint32_t thr, int64_t stride, double *u) {
     const int64_t m = static_cast<int64_t>(sched.size());
     const int64_t nb = (m + rows - 1) / rows, ns = (nb + stride - 1) / stride;
-    std::vector<int64_t> hot(static_cast<size_t>(ns), 0), all(static_cast<size_t>(ns), 0);
+    std::vector<int64_t> hot(static_cast<size_t>(ns), 0), all(static_cast<size_t>(ns), 0), staged(static_cast<size_t>(ns), 0);
     parallel_chunks(ns, [&](int64_t q) {
         const int64_t b = q * stride;
         std::vector<uint32_t> cols;
@@ -64,13 +64,14 @@ double estimate_hot_share(const flex_csr *A, const std::vector<uint32_t> &sched,
         for (size_t z = 0; z < cols.size();) {
             size_t z1 = z;
             while (z1 < cols.size() && cols[z1] == cols[z]) ++z1;
-            if (z1 - z >= thr) hot[q] += static_cast<int64_t>(z1 - z);
+            if (z1 - z >= thr) hot[q] += static_cast<int64_t>(z1 - z), ++staged[q];
             z = z1;
         }
         all[q] = static_cast<int64_t>(cols.size());
     });
-    int64_t h = 0, a = 0;
-    for (int64_t q = 0; q < ns; ++q) h += hot[q], a += all[q];
+    int64_t h = 0, a = 0, st = 0;
+    for (int64_t q = 0; q < ns; ++q) h += hot[q], a += all[q], st += staged[q];
+    if (u) *u = st > 0 ? static_cast<double>(h) / static_cast<double>(st) : 0.0;
     return a > 0 ? static_cast<double>(h) / static_cast<double>(a) : 0.0;
 }
 

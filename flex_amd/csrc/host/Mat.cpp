@@ -65,4 +65,8 @@ void Mat::alpha_stats_collect(FILE *stream) const {
     std::fprintf(stream, " Dense tiles: mean fill %.4f; %.1f%% of nnz in tiles of fill >= 0.10, %.1f%% >= 0.25, %.1f%% >= 0.50; MFMA route: %lld tiles, %.1f%% of nnz%s.\n",
                  s.tile_mean_fill, s.tile_nnz_pct_10, s.tile_nnz_pct_25, s.tile_nnz_pct_50, static_cast<long long>(s.mfma_tiles), s.mfma_nnz_pct,
                  s.mfma_tiles ? "" : " (vector kernel only)");
+    // reuse above the L2 (≙ the `u` of the reference's cost model, flex.cu:5513-5528, at the scope of one CU's LDS)
+    std::fprintf(stream, " LDS-level reuse in blocks of 480 rows: %.1f%% of nnz in columns used >= 2 times (u = %.1f), %.1f%% >= 4 times (u = %.1f); row blocks: %lld (%.1f%% of nnz, %.1f%% of them hot).\n",
+                 s.lds_hot_pct_2, s.lds_u_2, s.lds_hot_pct_4, s.lds_u_4, static_cast<long long>(i.n_blocks),
+                 i.nnz > 0 ? 100.0 * i.block_nnz / i.nnz : 0.0, i.block_nnz > 0 ? 100.0 * i.block_hot_nnz / i.block_nnz : 0.0);
 }

@@ -55,6 +55,7 @@ struct flex_plan {
     int64_t c_rows = 0;       // rows of C the plan writes into (m, or hostA->m for a mapped plan)
     int64_t device_bytes = 0;
     double plan_ms = 0;
+    double lds_hot[2] = {0, 0}, lds_u[2] = {0, 0};  // FLEX_PLAN_STATS: hot share and u of 480-row blocks at thr 2 / 4
     bool has_stats = false;
     flex_plan_stats stats{};
     flex_plan_tuning tuning{};  // the knobs this plan was built with, rules resolved (flex_plan_get_tuning)
@@ -148,7 +149,7 @@ struct BlockImage {  // host copy of what BlockView points at
 };
 // What share of the nonzeros of rows sched[...] would be HOT (their column used by >= thr nonzeros of the same block of `rows`
 // schedule-consecutive rows), looked at in every `stride`-th block: the planner's cheap look before it commits to the block route.
-double estimate_hot_share(const flex_csr *A, const std::vector<uint32_t> &sched, uint32_t rows, uint32_t thr, int64_t stride);
+double estimate_hot_share(const flex_csr *A, const std::vector<uint32_t> &sched, uint32_t rows, uint32_t thr, int64_t stride, double *u = nullptr);
 // Rows sched[0..) of A (a row's C row: dst_map, or r - r0) into blocks; `rest` receives the schedule positions that stay flat.
 int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const std::vector<uint32_t> &colpos, const int32_t *col_map,
                  const int32_t *dst_map, int32_t r0, uint32_t row_bytes32, const BlockKnobs &kn, BlockImage &img, std::vector<uint32_t> &rest);

@@ -72,6 +72,10 @@ class PlanBuilder {
         choose_tile_width();
         if ((rc = order_rows())) return rc;
         lap("row schedule");
+        if ((flags & FLEX_PLAN_STATS) && m > 0) {  // the reuse a workgroup could have above the L2 (flex_plan_stats.lds_*)
+            p->lds_hot[0] = 100.0 * estimate_hot_share(A, sched, 480, 2, 4, &p->lds_u[0]);
+            p->lds_hot[1] = 100.0 * estimate_hot_share(A, sched, 480, 4, 4, &p->lds_u[1]);
+        }
         if ((rc = route_dense_tiles())) return rc;
         lap("dense-tile detector");
         read_knobs();
@@ -766,6 +770,14 @@ static int build_with_blocks(flex_plan *p, const flex_csr *A, int32_t r0, int32_
     t2.mfma = 2;  // the dense-tile route and the block route do not combine (yet)
     rc = PlanBuilder(p, &A_rest, 0, static_cast<int32_t>(m_rest), col_map, dst.data(), (flags & ~FLEX_ORDER_MASK) | FLEX_ORDER_NATURAL, t2, nullptr, 0).run();
     if (rc) return rc;
+    if (flags & FLEX_PLAN_STATS) {  // the LDS-level reuse figures describe the WHOLE matrix, not the rows left to the flat planner
+        p->lds_hot[0] = 100.0 * estimate_hot_share(A, *sched, 480, 2, 4, &p->lds_u[0]);
+        p->lds_hot[1] = 100.0 * estimate_hot_share(A, *sched, 480, 4, 4, &p->lds_u[1]);
+        p->stats.lds_hot_pct_2 = p->lds_hot[0];
+        p->stats.lds_hot_pct_4 = p->lds_hot[1];
+        p->stats.lds_u_2 = p->lds_u[0];
+        p->stats.lds_u_4 = p->lds_u[1];
+    }
     p->order = order;
     p->c_rows = dst_map ? A->m : m;
     flex_plan_tuning &u = p->tuning;

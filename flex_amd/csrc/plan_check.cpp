@@ -58,6 +58,10 @@ void collect_stats(flex_plan *p, const RecordVec &rec, const std::vector<uint4> 
     st.tile_mean_fill = p->tile_cells > 0 ? all / (1024.0 * p->tile_cells) : 0.0;
     st.mfma_tiles = p->n_tiles;
     st.mfma_nnz_pct = all > 0 ? 100.0 * p->tile_nnz / all : 0.0;
+    st.lds_hot_pct_2 = p->lds_hot[0];
+    st.lds_hot_pct_4 = p->lds_hot[1];
+    st.lds_u_2 = p->lds_u[0];
+    st.lds_u_4 = p->lds_u[1];
     p->has_stats = true;
 }
 

@@ -247,6 +247,11 @@ typedef struct flex_plan_stats {
     double tile_mean_fill;  /* nnz / (1024 * non-empty tiles) */
     int64_t mfma_tiles;     /* tiles routed to the MFMA kernel */
     double mfma_nnz_pct;    /* share of the nonzeros they hold */
+    /* reuse a workgroup could have ABOVE the L2 (ABI 3): a column is hot in a block of 480 schedule-consecutive rows when
+       at least thr of the block's nonzeros use it -- those B rows could be staged in LDS once and used u times (≙ the `u` of the
+       reference's cost model, flex.cu:5513-5528, at the scope of one CU).  Every 4th block is looked at. */
+    double lds_hot_pct_2, lds_hot_pct_4; /* share of the nonzeros in hot columns, thr = 2 / 4 */
+    double lds_u_2, lds_u_4;             /* hot nonzeros per staged B row */
 } flex_plan_stats;
 int flex_plan_get_stats(const flex_plan *plan, flex_plan_stats *out);
 

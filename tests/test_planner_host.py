@@ -57,6 +57,10 @@ def test_one_d_plans_are_partitions(sim, k, order):
     info, st = p.info(), p.stats()
     assert info["nnz"] == a.nnz and info["n_chunks"] <= info["n_slots"] and st["records"] + info["tile_nnz"] >= a.nnz
     assert info["n_records"] == st["records"]
+    # the LDS-level reuse report (flex_plan_stats.lds_*): hot share falls and u rises with the threshold; a community order finds more
+    assert 0 <= st["lds_hot_pct_4"] <= st["lds_hot_pct_2"] <= 100 and (st["lds_hot_pct_4"] == 0 or st["lds_u_4"] >= max(4.0, st["lds_u_2"]))
+    if order == flex_amd.FLEX_ORDER_CLUSTER:
+        assert st["lds_hot_pct_2"] > 40 and st["lds_u_2"] >= 2
 
 
 def test_ragged_shapes_shards_maps_and_strides(sim):
