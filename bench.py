@@ -165,14 +165,9 @@ def main():
     timings = {"order_s": 0.0}
     rank_arr, cache_state = None, None
     if args.perm_cache and args.order != "natural":
-        fp = flex_amd.csr_fingerprint(a)
-        try:
-            rank_arr, cache_state = flex_amd.perm_load(args.perm_cache, a.m, fp), "loaded"
-        except flex_amd.FlexError:
-            rank_arr = flex_amd.multigpu.shared_ordering(a, args.order, timings)
-            cache_state = "written"
-            if rank == 0:
-                flex_amd.perm_save(args.perm_cache, rank_arr, fp)
+        # only rank 0 reads or writes the file; every rank joins the one broadcast (flex_amd/multigpu.py, shared_ordering)
+        rank_arr = flex_amd.multigpu.shared_ordering(a, args.order, timings, cache=args.perm_cache)
+        cache_state = timings.get("perm_cache")
     if world == 1 and not args.dry_run:
         want_stats = a.nnz <= 50_000_000  # one extra pass over the records: skipped on amazon-size inputs
         flags = (flex_amd.FLEX_PLAN_STATS if want_stats else 0) | (flex_amd.FLEX_PLAN_AUTOTUNE if args.autotune else 0)

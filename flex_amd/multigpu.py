@@ -57,13 +57,32 @@ class RowShard:
 ORDERINGS = {"rcm": _b.order_rcm, "cluster": _b.order_cluster, "deg": _b.order_deg, "gorder": _b.order_gorder, "dfs": _b.order_dfs}
 
 
-def shared_ordering(a: "_b.HostCsr", order: str, timings: dict | None = None) -> np.ndarray:
+def shared_ordering(a: "_b.HostCsr", order: str, timings: dict | None = None, cache: str | None = None) -> np.ndarray:
     """rank[old] = new for `a`, computed ONCE per job: with torch.distributed up, rank 0 runs the ordering (the community order
     of the Amazon shape is 2 s on 32 threads and 4 GB of scratch) and broadcasts the 4n bytes; the other ranks only receive.
-    Without a process group (one process), computed here.  timings["order_s"] = seconds THIS rank spent ordering."""
+    Without a process group (one process), computed here.  timings["order_s"] = seconds THIS rank spent ordering.
+    cache: a permutation-cache file (flex_perm_save / _load, keyed by the matrix's fingerprint).  ONLY rank 0 touches it -- loads it if
+    it matches, else orders and writes it -- so the ranks cannot disagree about whether there is a collective to join (a rank that
+    found the file another rank had just written would skip the broadcast the others are waiting in).  timings["perm_cache"] =
+    "loaded" / "written" (rank 0; the others report what rank 0 did)."""
     import time
     t0 = time.perf_counter()
     spent = 0.0
+
+    def order_or_load():
+        nonlocal spent
+        if cache:
+            fp = _b.csr_fingerprint(a)
+            try:
+                return _b.perm_load(cache, a.m, fp), 1
+            except _b.FlexError:
+                pass
+        r = ORDERINGS[order](a)
+        spent = time.perf_counter() - t0
+        if cache:
+            _b.perm_save(cache, r, fp)
+        return r, (2 if cache else 0)
+
     try:
         import torch
         import torch.distributed as dist
@@ -71,20 +90,20 @@ def shared_ordering(a: "_b.HostCsr", order: str, timings: dict | None = None) ->
     except ImportError:
         group = False
     if not group:
-        rank_arr = ORDERINGS[order](a)
-        spent = time.perf_counter() - t0
+        rank_arr, state = order_or_load()
     else:
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
         if dist.get_rank() == 0:
-            rank_arr = ORDERINGS[order](a)
-            spent = time.perf_counter() - t0
-            buf = torch.from_numpy(rank_arr.astype(np.int32)).to(dev)
+            rank_arr, state = order_or_load()
+            buf = torch.cat([torch.from_numpy(rank_arr.astype(np.int32)), torch.tensor([state], dtype=torch.int32)]).to(dev)
         else:
-            buf = torch.empty(a.m, dtype=torch.int32, device=dev)
+            buf = torch.empty(a.m + 1, dtype=torch.int32, device=dev)
         dist.broadcast(buf, src=0)
-        rank_arr = buf.cpu().numpy().astype(np.uint32)
+        host = buf.cpu().numpy()
+        rank_arr, state = host[: a.m].astype(np.uint32), int(host[a.m])
     if timings is not None:
         timings["order_s"] = spent
+        timings["perm_cache"] = {0: None, 1: "loaded", 2: "written"}[state]
     return rank_arr
 
 
