@@ -26,9 +26,11 @@
 //    wave-uniform scalar check after each step flushes the accumulator when a row
 //    ends.  No barriers: LDS slices are private to a wave.
 //  * C is written once with non-temporal 16-byte stores; rows cut into several
-//    pieces go to k-wide partial slots instead and are summed, in a fixed order,
-//    by whichever piece finishes last, inside the same launch (deterministic; the
-//    reference uses atomicAdd for its split rows, mat.cu:816-824).
+//    pieces go to k-wide partial slots instead and are summed in piece order -- by
+//    spmm_fixup_kernel after this launch (the default since ABI 3: it needs nothing
+//    beyond stream order) or, on request (flex_plan_tuning.split_rows = 1), by
+//    whichever piece finishes last inside the same launch.  Deterministic either way;
+//    the reference uses atomicAdd for its split rows, mat.cu:816-824.
 #include "internal.h"
 
 namespace flex {
@@ -407,7 +409,8 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
     // task i's row (agent-scope atomic; t_aux = {row's index in `split`, #pieces}); (4) a lane whose add returns
     // count-1 knows every piece of that row is visible: the wave reads them with sc1 loads (never through a CU's
     // L1) and adds them in PIECE order -- the sum is reproducible although the reducer is not -- S rows at a time,
-    // one per slot, and re-arms the counters for the next launch.
+    // one per slot, and re-arms the counters for the next launch.  OPT-IN since ABI 3 (p.fused_fixup): by default the
+    // pieces are left to spmm_fixup_kernel, which measured faster on the large shapes and needs no such argument.
     // Why RELAXED + sc1 instead of an acq_rel atomic: a release at agent scope is `buffer_wbl2 sc1`, a
     // write-back of the whole XCD L2 (1.7-6.5 us, MI355X_MICROARCH.md "Workgroup dispatch ... visibility"),
     // paid by every chunk.  The form used here is that guide's hand-off "each storing wave for itself:
