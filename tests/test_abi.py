@@ -304,3 +304,17 @@ def test_rabbit_order_equals_oracle_restatement():
     rows = np.repeat(np.arange(g.m), np.diff(g.rowPtr.astype(np.int64)))
     rk = flex_amd.order_rabbit(g).astype(np.int64)
     assert np.mean(np.abs(rk[rows] - rk[g.col]) <= 64) > 3 * np.mean(np.abs(rows - g.col.astype(np.int64)) <= 64)
+
+
+def test_the_library_reads_no_tuning_knob_from_the_environment():
+    """ABI 3: plan-time knobs are fields of flex_plan_tuning.  The library's sources may call getenv for FLEX_PLAN_TIMING only (phase
+    times on stderr); rounds 1-2 read ~25 knobs that way (process-global, racy between concurrent flex_plan_create calls)."""
+    import glob
+    hits = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "flex_amd", "csrc", "*.cpp")) + glob.glob(os.path.join(ROOT, "flex_amd", "csrc", "*.h"))
+                    + glob.glob(os.path.join(ROOT, "flex_amd", "csrc", "*.hip"))):
+        for n, line in enumerate(open(f, encoding="utf-8"), 1):
+            code = line.split("//", 1)[0]
+            if "getenv" in code:
+                hits.append((os.path.basename(f), n, code.strip()))
+    assert len(hits) == 1 and "FLEX_PLAN_TIMING" in hits[0][2], hits

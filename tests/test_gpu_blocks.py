@@ -137,3 +137,40 @@ def test_row_blocks_are_stable_under_repetition():
             assert torch.equal(C, ref), f"launch {it}: result changed"
     torch.cuda.synchronize()
     assert torch.equal(C, ref)
+
+
+def test_row_blocks_in_a_hip_graph_and_on_two_streams():
+    """flex_spmm with a block plan is two kernel launches (row blocks + the flat rest; + the fix-up when the rest has split rows),
+    no allocation, no host sync: it can be captured in a hipGraph; and two block plans on two streams do not disturb each other."""
+    g = flex_amd.synth_graph(n=20000, nnz=20000 + 2 * 500000, community=400, p_in=0.6, p_near=0.25, seed=22)
+    a = random_csr(9000, 9000, 20, seed=33, long_rows={5: 8000, 77: 1200}, empty_frac=0.05)
+    k = 128
+    Bg, Ba = random_B(g.n, k, 1), random_B(a.n, k, 2)
+    pg = Plan(g, k, order=flex_amd.FLEX_ORDER_CLUSTER, tuning=BLOCKS)
+    pa = Plan(a, k, tuning=dict(BLOCKS, block_cap=30))
+    assert pg.info()["n_blocks"] > 0 and pa.info()["n_blocks"] > 0 and pa.info()["n_split_rows"] > 0
+    dg, da = dev(Bg), dev(Ba)
+    Cg = torch.zeros((g.m, k), device="cuda")
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        pg(dg, out=Cg)  # warm-up outside capture
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        pg(dg, out=Cg)
+    Cg.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    ref_g = Cg.cpu().numpy()
+    assert_matches_oracle(g, Bg, ref_g)
+    ref_a = run_plan(pa, Ba)
+    assert_matches_oracle(a, Ba, ref_a)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    Ca = torch.empty((a.m, k), device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(30):
+        pg.spmm(dg.data_ptr(), Cg.data_ptr(), s1.cuda_stream)
+        pa.spmm(da.data_ptr(), Ca.data_ptr(), s2.cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(Cg.cpu().numpy(), ref_g) and np.array_equal(Ca.cpu().numpy(), ref_a)
