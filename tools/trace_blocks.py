@@ -16,7 +16,7 @@ binding._SO = os.path.join(os.path.dirname(binding._SO), "libflex_spmm_trace.so"
 import flex_amd  # noqa: E402
 
 name, k = sys.argv[1], int(sys.argv[2])
-rounds, prow, thr, cap = (int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "4:480:3:0").split(":"))
+rounds, prow, thr, cap, abl = (list(int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "4:480:3:0").split(":")) + [0])[:5]
 gen = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in os.environ.get("GEN", "").split(",") if kv}
 if gen:
     sp = flex_amd.synth_preset(name)
@@ -25,7 +25,7 @@ if gen:
                              gcn_norm=bool(sp.gcn_norm), seed=sp.seed)
 else:
     a = flex_amd.synth_graph(name)
-p = flex_amd.Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER, tuning={"blocks": 1, "block_rounds": rounds, "block_panel_rows": prow, "block_thr": thr, "block_cap": cap})
+p = flex_amd.Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER, tuning={"blocks": 1, "block_rounds": rounds, "block_panel_rows": prow, "block_thr": thr, "block_cap": cap, "block_ablate": abl})
 i = p.info()
 nb, ktiles = i["n_blocks"], (k + 31) // 32
 B = torch.rand((a.n, k), device="cuda") * 2 - 1
