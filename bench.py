@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-copy-probe", action="store_true", help="skip the streaming read / copy probe that measures achievable HBM GB/s")
     ap.add_argument("--no-vendor", action="store_true", help="skip the hipSPARSE side-by-side (N=1 only)")
+    ap.add_argument("--no-live-counters", action="store_true",
+                    help="do not read the card's memory counters inside the run (N=1 reads them by default, after the timed region: "
+                         "flex_amd/counters.py); roofline.traffic then falls back to the committed rocprofv3 figure")
     ap.add_argument("--check", action="store_true", help="verify rank 0's shard against the oracle (small workloads)")
     ap.add_argument("--shrink", type=int, default=1, help="rehearsals only: the preset with n and nnz divided by this (same generator and code path)")
     ap.add_argument("--host-threads", type=int, default=0, help="worker threads of the planner / orderings / generator in THIS process "
@@ -69,8 +72,26 @@ def parse():
     return ap.parse_args()
 
 
+def _under_a_profiler():
+    """rocprofv3 (or any other rocprofiler-sdk tool) already owns the counters of this process: two clients programming the same
+    hardware counters is the combination to stay away from."""
+    pre = os.environ.get("LD_PRELOAD", "")
+    return bool(os.environ.get("ROCP_TOOL_LIBRARIES")) or "rocprofiler" in pre or "rocprofv3" in pre
+
+
 def main():
     args = parse()
+    # In-run memory counters (≙ the NPerf metrics of the reference's run(), flex.cu:4583-4656): the profiler has to be asked for
+    # BEFORE the first HIP call of the process.  N=1 only (one process, one card), never under rocprofv3, never in a dry run.
+    live = None
+    if args.gpus == 1 and not args.dry_run and not args.no_live_counters and not _under_a_profiler():
+        try:
+            from flex_amd import counters as live
+            live.init()
+        except Exception as e:  # noqa: BLE001 -- the measurement must not depend on the profiler being usable
+            print(f"bench.py: in-run counters unavailable ({type(e).__name__}: {e}); roofline.traffic falls back to profiles/pmc_traffic.json",
+                  file=sys.stderr, flush=True)
+            live = None
     import torch
     import torch.distributed as dist
 
@@ -244,6 +265,26 @@ def main():
         per_rank = [[float(x) for x in t_.tolist()] for t_ in allr]
         wall, dev_ms = max(r[0] for r in per_rank), max(r[1] for r in per_rank)
 
+    # ---- in-run counters, AFTER the timed region (N=1): the same launches again, one pass per counter set; the card is
+    # otherwise idle, so the card-wide sums are this kernel's
+    counted = None
+    if live is not None and world == 1:
+        try:
+            n_cnt = max(1, min(args.steps, 10 if shard_nnz > 1e8 else 30))
+
+            def launches():
+                for _ in range(n_cnt):
+                    plan.spmm(bp, cp, stream)
+
+            counted = live.traffic(launches, device=local_rank, sync=torch.cuda.synchronize, launches=n_cnt)
+            l2 = live.count(launches, live.L2_PASS, device=local_rank, sync=torch.cuda.synchronize)
+            counted["l2_hit_rate"] = l2["TCC_HIT_sum"] / max(1.0, l2["TCC_HIT_sum"] + l2["TCC_MISS_sum"])
+            counted["launches_per_pass"] = n_cnt
+        except Exception as e:  # noqa: BLE001
+            print(f"bench.py: in-run counters failed ({type(e).__name__}: {e}); roofline.traffic falls back to profiles/pmc_traffic.json",
+                  file=sys.stderr, flush=True)
+            counted = None
+
     ok = None
     if args.check and rank == 0:
         import oracle
@@ -289,7 +330,13 @@ def main():
                 "tpre_over_telap": round(t_plan * 1e3 / max(kern_ms, 1e-9), 1),
             },
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic(args, world),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         # HBM-side bytes of ONE launch: read inside this run from the card's counters when possible (N=1), else
+                         # the committed rocprofv3 figure while it applies to the running sources, else null
+                         "traffic": int(counted["traffic_bytes"]) if counted else _pmc_traffic(args, world),
+                         "traffic_source": (f"in-run: rocprofiler-sdk device counting service, {counted['launches_per_pass']} launches per pass after the "
+                                            "timed region, 2*FETCH_SIZE + WRITE_SIZE (KiB)" if counted else
+                                            "profiles/pmc_traffic.json (rocprofv3 --pmc passes of tools/pmc.sh)" if _pmc_traffic(args, world) is not None else None),
                          "kernel": "spmm_block_kernel + spmm_flat_kernel" if info.get("n_blocks", 0) else "spmm_flat_kernel", "kernel_ms": round(kern_ms, 6),
                          "algorithmic_bytes_per_launch": int(b_alg),
                          # what the flat kernel asks of the texture path: every record pulls one B-row segment of 16*G
@@ -302,6 +349,17 @@ def main():
         }
         # the fabric term of DESIGN.md 3.4: the launch's L2-miss traffic (committed PMC figure, when it applies to the running
         # sources) at the 6.3 TB/s the fabric delivers
+        if counted:
+            # ≙ the reference's per-row DRAM bytes, L2 figures and measured B reuse u (flex.cu:5237, 5513-5528: nD = 4/u + ...):
+            # u = B bytes the nonzeros ask for / bytes the L2s fetched beyond A's own
+            out["roofline"]["traffic_read_bytes"] = int(counted["read_bytes"])
+            out["roofline"]["traffic_write_bytes"] = int(counted["write_bytes"])
+            out["roofline"]["traffic_over_algorithmic"] = round(counted["traffic_bytes"] / b_alg, 2)
+            out["roofline"]["l2_hit_rate"] = round(counted["l2_hit_rate"], 4)
+            b_fetched = counted["read_bytes"] - 8.0 * shard_nnz - 4.0 * (shard_rows + 1)
+            # null when the L2s served (nearly) everything: a graph whose A and B stay resident in 32 MiB of L2 fetches no B at all
+            out["roofline"]["u_measured"] = round(4.0 * shard_nnz * k / b_fetched, 3) if b_fetched > 0.01 * 4.0 * a.n * k else None
+            out["roofline"]["traffic_rocprofv3_committed"] = _pmc_traffic(args, world)  # the offline figure for the same sources, or null
         if out["roofline"]["traffic"] is not None:
             out["roofline"]["model_fabric_ms"] = round(out["roofline"]["traffic"] / 6.3e12 * 1e3, 6)
             # the north_star's "rocprof-measured HBM GB/s against the chip's peak": PMC bytes of the launch (memory side of

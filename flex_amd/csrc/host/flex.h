@@ -14,8 +14,12 @@ struct RunOptions {
     bool debug_values = false;   // ≙ opt_debug (DataLoader.cu:7, 51, 202-203): every A value 1, X[i][*] = i -- results readable by eye
     bool axw = false;            // run the GCN layer product A*X*W both ways instead of the SpMM loop (main.cu:22-77)
     int gpus = 0;                // > 0: also run the row-sharded multi-GPU path on that many devices (flex_mg.h)
+    bool counters = false;       // read the card's memory counters around each configuration's launches (≙ the NPerf metrics of
+                                 // flex.cu:4583-4656): HBM-side bytes, L2 hit rate and the measured B reuse u as table columns
 };
 RunOptions &run_options();
+// --counters: loads libflex_counters.so (include/flex_counters.h) and asks for the profiler; must run before the first HIP call
+void counters_attach();
 
 void run(DataLoader &input);                      // ≙ flex.cu:4560-5716: bench loop over orderings
 void cuSpmm(DataLoader &input, Perfs &perfRes);   // ≙ flex.cu:5717-5804: vendor SpMM (hipSPARSE) -> input.gpuC

@@ -1,5 +1,5 @@
 // main.cpp (host mirror) -- ≙ main.cu:7-83 (the non-AXW path): flex <csv|synth:name[*scale]> <k>
-// [--iters N] [--warmup N] [--json] [--stats] [--perm-cache DIR] [--csv FILE] [--stats-log FILE] [--no-vendor] [--gpus N] [--axw] [--debug-values]
+// [--iters N] [--warmup N] [--json] [--stats] [--perm-cache DIR] [--csv FILE] [--stats-log FILE] [--no-vendor] [--gpus N] [--axw] [--debug-values] [--counters]
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -9,7 +9,7 @@
 
 int main(int argc, char *argv[]) {
     if (argc < 3) {
-        std::fprintf(stderr, "usage: %s <graph.csv | synth:name[*scale]> <k> [--iters N] [--warmup N] [--json] [--stats] [--perm-cache DIR] [--csv FILE] [--stats-log FILE] [--no-vendor] [--gpus N] [--axw] [--debug-values]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <graph.csv | synth:name[*scale]> <k> [--iters N] [--warmup N] [--json] [--stats] [--perm-cache DIR] [--csv FILE] [--stats-log FILE] [--no-vendor] [--gpus N] [--axw] [--debug-values] [--counters]\n", argv[0]);
         return 2;
     }
     for (int i = 3; i < argc; ++i) {
@@ -17,6 +17,7 @@ int main(int argc, char *argv[]) {
         else if (!std::strcmp(argv[i], "--stats")) run_options().stats = true;
         else if (!std::strcmp(argv[i], "--axw")) run_options().axw = true;
         else if (!std::strcmp(argv[i], "--debug-values")) run_options().debug_values = true;
+        else if (!std::strcmp(argv[i], "--counters")) run_options().counters = true;
         else if (!std::strcmp(argv[i], "--perm-cache") && i + 1 < argc) run_options().perm_cache = argv[++i];
         else if (!std::strcmp(argv[i], "--csv") && i + 1 < argc) run_options().csv = argv[++i];
         else if (!std::strcmp(argv[i], "--stats-log") && i + 1 < argc) run_options().stats_log = argv[++i];
@@ -27,6 +28,7 @@ int main(int argc, char *argv[]) {
         else { std::fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
     try {
+        if (run_options().counters) counters_attach();  // before the loader makes the first HIP call
         DataLoader data(argv[1], std::atoi(argv[2]));
         std::cout << "Graph name: " << data.graph_name << std::endl;
         std::cout << "A: " << data.n << "*" << data.n << "  X: " << data.n << "*" << data.dim << "   W: " << data.dim

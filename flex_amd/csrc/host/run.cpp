@@ -2,6 +2,8 @@
 // 4154-4213).  Same loop shape -- vendor gold first, then one (ordering x schedule) configuration
 // after another: plan, launch_prep, warm-up, timed launches, copy back, resCheck, free -- with
 // NPerf/pTable replaced by HIP events and printf, and GFLOP/s = 2e-9*nnz*k/t (flex.cu:5629).
+#include <dlfcn.h>
+
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -14,6 +16,46 @@
 RunOptions &run_options() {
     static RunOptions o;
     return o;
+}
+
+// libflex_counters.so is loaded only on request (and with RTLD_GLOBAL: the ROCm runtime looks its rocprofiler_configure up
+// over the whole process when it initialises), so a run without --counters never has the profiler in the process.
+namespace {
+struct CountersLib {
+    int (*init)() = nullptr;
+    int (*begin)(int, const char *const *, int) = nullptr;
+    int (*end)(double *) = nullptr;
+    const char *(*error)() = nullptr;
+} g_counters;
+
+// one pass around `launches` launches of `mat`; returns the per-launch sums (false + message on stderr when the profiler refuses)
+bool counted(Mat &mat, int launches, const char *const *names, int n, double *out) {
+    HIP_CHECK(hipDeviceSynchronize());
+    if (g_counters.begin(0, names, n) != 0) {
+        std::fprintf(stderr, "flex --counters: %s\n", g_counters.error());
+        return false;
+    }
+    for (int i = 0; i < launches; ++i) mat.launch();
+    HIP_CHECK(hipDeviceSynchronize());
+    if (g_counters.end(out) != 0) {
+        std::fprintf(stderr, "flex --counters: %s\n", g_counters.error());
+        return false;
+    }
+    for (int i = 0; i < n; ++i) out[i] /= launches;
+    return true;
+}
+}  // namespace
+
+void counters_attach() {
+    void *h = dlopen("libflex_counters.so", RTLD_NOW | RTLD_GLOBAL);  // next to the binary (RUNPATH $ORIGIN)
+    if (!h) throw std::runtime_error(std::string("--counters: ") + dlerror());
+    g_counters.init = reinterpret_cast<int (*)()>(dlsym(h, "flex_counters_init"));
+    g_counters.begin = reinterpret_cast<int (*)(int, const char *const *, int)>(dlsym(h, "flex_counters_begin"));
+    g_counters.end = reinterpret_cast<int (*)(double *)>(dlsym(h, "flex_counters_end"));
+    g_counters.error = reinterpret_cast<const char *(*)()>(dlsym(h, "flex_counters_error"));
+    if (!g_counters.init || !g_counters.begin || !g_counters.end || !g_counters.error)
+        throw std::runtime_error("--counters: libflex_counters.so lacks an entry point of include/flex_counters.h");
+    if (g_counters.init() != 0) throw std::runtime_error(std::string("--counters: ") + g_counters.error());
 }
 
 void cuSpmm(DataLoader &input, Perfs &perfRes) {
@@ -94,6 +136,10 @@ struct Row {
     flex_plan_info info;
     flex_plan_stats stats;
     flex_imbalance imb;  // ≙ the "Imb" column (flex.cu:5087-5126): one stamped launch after the timed ones
+    // --counters (≙ the DRAM GB/s, %Pk and measured-u columns, flex.cu:5237, 5513-5528): HBM-side bytes per launch
+    // (2 x FETCH_SIZE + WRITE_SIZE in KiB: the gfx950 correction of MI355X_MICROARCH "HBM"), L2 hit rate, and
+    // u = B bytes the nonzeros ask for / bytes the L2 fetched beyond A's; all < 0 when not measured
+    double hbm_bytes = -1, l2_hit = -1, u_meas = -1;
 };
 
 void bench_one(DataLoader &dl, unsigned schedule, const char *sched_name, const DataLoader &gold_src, float *h_res,
@@ -131,10 +177,21 @@ void bench_one(DataLoader &dl, unsigned schedule, const char *sched_name, const 
     if (!gold_src.h_ref_c.empty()) errs = resCheck(gold_src.h_ref_c.data(), h_res, mat, perfRes, &max_err);
     const double flops = 2.0 * dl.nnz * dl.dim;
     const double balg = (double(dl.n) + 1 + 2.0 * dl.nnz + 2.0 * dl.n * dl.dim) * 4;  // flex.cu:4672, 5795
+    double hbm_bytes = -1, l2_hit = -1, u_meas = -1;
+    if (o.counters) {  // after the timed launches: three passes (the TCC block cannot hold FETCH_SIZE and WRITE_SIZE at once)
+        const char *fetch[] = {"FETCH_SIZE"}, *write[] = {"WRITE_SIZE"}, *l2[] = {"TCC_HIT_sum", "TCC_MISS_sum"};
+        double f = 0, w = 0, hm[2] = {0, 0};
+        if (counted(mat, o.iters, fetch, 1, &f) && counted(mat, o.iters, write, 1, &w) && counted(mat, o.iters, l2, 2, hm)) {
+            const double rd = 2.0 * 1024.0 * f, a_bytes = 8.0 * dl.nnz + 4.0 * (dl.n + 1);
+            hbm_bytes = rd + 1024.0 * w;
+            l2_hit = hm[0] / std::max(1.0, hm[0] + hm[1]);
+            if (rd - a_bytes > 0.01 * 4.0 * dl.n * dl.dim) u_meas = 4.0 * dl.nnz * dl.dim / (rd - a_bytes);  // else: the L2s held B, nothing to divide by
+        }
+    }
     flex_imbalance imb{};
     if (flex_plan_measure_imbalance(mat.plan, mat.mat_b_dev, mat.mat_c_dev, nullptr, &imb) != FLEX_OK) imb = flex_imbalance{};  // odd k: no stamped twin
     rows.push_back({dl.vertex_order_abbr, sched_name, t_us, flops / t_us * 1e-3, balg / t_us * 1e-3,
-                    mat.info().plan_ms, max_err, errs, mat.info(), mat.stats(), imb});
+                    mat.info().plan_ms, max_err, errs, mat.info(), mat.stats(), imb, hbm_bytes, l2_hit, u_meas});
     perfRes.flex_spmm_time.push_back(static_cast<float>(t_us * 1e-3));
     mat.alpha_freeMatGPU();
 }
@@ -210,16 +267,21 @@ void run(DataLoader &input_vo) {
                     r.sched.c_str(), r.t_us, r.gflops, r.balg_gbs, r.balg_gbs / 8000.0 * 100,
                     static_cast<long long>(r.info.n_chunks), static_cast<long long>(r.info.n_split_rows),
                     r.stats.reuse_wave, r.stats.reuse_xcd, r.imb.cu_busy_imb_pct, r.plan_ms, r.plan_ms * 1e3 / r.t_us, r.errs);
+        if (r.hbm_bytes >= 0)  // ≙ the reference's DRAM GB/s, %Pk and measured u per table row (flex.cu:5237)
+            std::printf("     counters: HBM-side %.1f MB/launch = %.2fx Balg, %.0f GB/s (%.1f %% of 8 TB/s), L2 hit %.3f, u %.2f\n",
+                        r.hbm_bytes * 1e-6, r.hbm_bytes / (r.balg_gbs * r.t_us * 1e3), r.hbm_bytes / r.t_us * 1e-3,
+                        r.hbm_bytes / r.t_us * 1e-3 / 8000.0 * 100, r.l2_hit, r.u_meas);
         if (o.json)
             std::printf("{\"graph\":\"%s\",\"n\":%zu,\"nnz\":%zu,\"k\":%zu,\"ord\":\"%s\",\"schedule\":\"%s\",\"t_us\":%.3f,"
                         "\"gflops\":%.2f,\"balg_gbs\":%.2f,\"max_err\":%.3g,\"errs\":%d,\"vendor_us\":%.3f,\"b_re1\":%.3f,\"b_re2\":%.3f,"
                         "\"chunk_imb_pct\":%.1f,\"xcd_imb_pct\":%.2f,\"cu_imb_pct\":%.2f,\"cu_end_spread_pct\":%.2f,\"xcd_busy_imb_pct\":%.2f,"
-                        "\"cus_seen\":%d,\"plan_ms\":%.2f,\"tpre_over_telap\":%.1f,\"mfma_tiles\":%lld,\"tile_nnz_pct_25\":%.2f}\n",
+                        "\"cus_seen\":%d,\"plan_ms\":%.2f,\"tpre_over_telap\":%.1f,\"mfma_tiles\":%lld,\"tile_nnz_pct_25\":%.2f,"
+                        "\"hbm_bytes\":%.0f,\"l2_hit\":%.4f,\"u_measured\":%.3f}\n",
                         input_vo.graph_name.c_str(), input_vo.n, input_vo.nnz, input_vo.dim, r.ord.c_str(),
                         r.sched.c_str(), r.t_us, r.gflops, r.balg_gbs, r.max_err, r.errs, perfRes.cuSpmmProcessing,
                         r.stats.reuse_wave, r.stats.reuse_xcd, r.stats.chunk_imb_pct, r.stats.xcd_imb_pct, r.imb.cu_busy_imb_pct,
                         r.imb.cu_end_spread_pct, r.imb.xcd_busy_imb_pct, r.imb.cus_seen, r.plan_ms, r.plan_ms * 1e3 / r.t_us,
-                        static_cast<long long>(r.stats.mfma_tiles), r.stats.tile_nnz_pct_25);
+                        static_cast<long long>(r.stats.mfma_tiles), r.stats.tile_nnz_pct_25, r.hbm_bytes, r.l2_hit, r.u_meas);
     }
     int mg_errs = 0;
     if (o.gpus > 0) {  // row-sharded over several GPUs (new; the reference is single-GPU, flex.cu:4137)

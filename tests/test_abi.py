@@ -23,7 +23,8 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 
 @pytest.mark.parametrize("header,lib", [("flex_spmm.h", "libflex_spmm.so"), ("flex_vendor.h", "libflex_vendor.so"),
-                                        ("flex_mg.h", "libflex_mg.so"), ("flex_axw.h", "libflex_axw.so")])
+                                        ("flex_mg.h", "libflex_mg.so"), ("flex_axw.h", "libflex_axw.so"),
+                                        ("flex_counters.h", "libflex_counters.so")])
 def test_every_header_symbol_is_exported_by_its_library(header, lib):
     """include/*.h is the drop-in boundary: each declared entry point must be a defined dynamic symbol of
     the library named for it (read with nm, so nothing needs a GPU or the vendor runtimes to load)."""
@@ -38,7 +39,7 @@ def test_every_header_symbol_is_exported_by_its_library(header, lib):
 
 
 def test_all_headers_are_covered():
-    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["flex_axw.h", "flex_mg.h", "flex_spmm.h", "flex_vendor.h"]
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["flex_axw.h", "flex_counters.h", "flex_mg.h", "flex_spmm.h", "flex_vendor.h"]
 
 
 def test_no_cpu_spmm_symbol_in_product():

@@ -1,0 +1,129 @@
+"""The in-run memory counters (include/flex_counters.h, libflex_counters.so, flex_amd/counters.py): ≙ the NPerf metrics the
+reference's run() collects per table row (flex.cu:4583-4656, 5237).  The profiler must be asked for before the first HIP call of
+a process, so every GPU case runs in a child process of its own (pytest's process has long touched the card)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def test_counters_refuse_to_count_without_a_profiler():
+    """CPU: the library loads, init is accepted (the profiler would come up with the runtime) and begin fails loudly -- never a
+    silent pass that reports zeros."""
+    from flex_amd import counters
+    counters.init()
+    assert counters.devices() == 0
+    with pytest.raises(counters.CountersError, match="not up"):
+        counters.begin(["FETCH_SIZE"])
+    with pytest.raises(counters.CountersError, match="no pass is open"):
+        counters.end(1)
+
+
+CHILD = r"""
+import json, os, sys
+sys.path.insert(0, %(root)r)
+from flex_amd import counters
+late = len(sys.argv) > 1 and sys.argv[1] == "late"
+import torch
+if late:
+    torch.zeros(1, device="cuda")  # the runtime is up before anybody asked for the profiler
+if late:
+    try:
+        counters.init()
+        counters.begin(["FETCH_SIZE"])
+    except counters.CountersError as e:
+        print(json.dumps({"late_error": str(e)}))
+        sys.exit(0)
+    print(json.dumps({"late_error": None}))
+    sys.exit(0)
+counters.init()
+import flex_amd
+sync = torch.cuda.synchronize
+torch.zeros(1, device="cuda")
+out = {"gpus": counters.devices()}
+src = torch.empty(1 << 28, dtype=torch.float32, device="cuda").normal_()  # 1 GiB
+dst = torch.empty_like(src)
+t = counters.traffic(lambda: dst.copy_(src), sync=sync)
+out["copy_read_ratio"], out["copy_write_ratio"] = t["read_bytes"] / (1 << 30), t["write_bytes"] / (1 << 30)
+try:
+    counters.begin(["FETCH_SIZE", "WRITE_SIZE"])  # 3 + 2 of the TCC block's 4 slots: one pass cannot hold both
+    counters.end(2)
+    out["both_in_one_pass"] = "accepted"
+except counters.CountersError as e:
+    out["both_in_one_pass"] = str(e)
+try:
+    counters.begin(["NO_SUCH_COUNTER"])
+    out["bad_name"] = "accepted"
+except counters.CountersError as e:
+    out["bad_name"] = str(e)
+del src, dst
+a = flex_amd.synth_graph("flickr")
+k = 128
+B = torch.rand((a.n, k), device="cuda") * 2 - 1
+C = torch.empty((a.m, k), device="cuda")
+plan = flex_amd.Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER)
+s = torch.cuda.current_stream().cuda_stream
+for _ in range(3):
+    plan.spmm(B.data_ptr(), C.data_ptr(), s)
+n = 20
+def steps():
+    for _ in range(n):
+        plan.spmm(B.data_ptr(), C.data_ptr(), s)
+t1 = counters.traffic(steps, sync=sync, launches=n)
+t2 = counters.traffic(steps, sync=sync, launches=n)
+out.update(read=t1["read_bytes"], write=t1["write_bytes"], read2=t2["read_bytes"], m=a.m, n=a.n, nnz=a.nnz, k=k)
+print(json.dumps(out))
+"""
+
+
+def _child(*argv):
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, *argv], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+def test_counters_match_known_byte_counts_and_bound_the_spmm_launch():
+    """Calibration in the engine's own access width (16 B per lane): a 1 GiB copy must read and write 1 GiB through the
+    corrected counters (2 x FETCH_SIZE, WRITE_SIZE, both KiB).  Then one SpMM launch: C is written exactly once, the reads
+    cover at least A and at most what the texture path asks for, and two measurements of the same launch agree."""
+    o = _child()
+    assert o["gpus"] >= 1
+    assert abs(o["copy_read_ratio"] - 1) < 0.01 and abs(o["copy_write_ratio"] - 1) < 0.01, o
+    assert "accepted" not in o["both_in_one_pass"] and "accepted" not in o["bad_name"] and "NO_SUCH_COUNTER" in o["bad_name"], o
+    c_bytes, a_bytes, b_bytes = 4.0 * o["m"] * o["k"], 8.0 * o["nnz"] + 4.0 * (o["m"] + 1), 4.0 * o["n"] * o["k"]
+    assert 0.98 * c_bytes <= o["write"] <= 1.10 * c_bytes, o          # split-row partials add a little
+    assert 0.9 * (a_bytes + b_bytes) <= o["read"] <= a_bytes + 4.0 * o["nnz"] * o["k"], o
+    assert abs(o["read"] - o["read2"]) <= 0.05 * o["read"], o
+
+
+@pytest.mark.gpu
+def test_counters_asked_for_too_late_fail_loudly():
+    o = _child("late")
+    assert o["late_error"] and ("not up" in o["late_error"] or "before flex_counters_init" in o["late_error"]), o
+
+
+@pytest.mark.gpu
+def test_cli_prints_measured_bytes_per_table_row():
+    """`flex --counters`: every (ordering, schedule) row of the table carries the HBM-side bytes, L2 hit rate and u measured
+    around its own launches (≙ the DRAM / L2 / u columns of the reference's table, flex.cu:5237), results still checked."""
+    exe = os.path.join(ROOT, "flex_amd", "lib", "flex")
+    r = subprocess.run([exe, "synth:flickr", "32", "--counters", "--json", "--iters", "5"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(rows) >= 7 and all(x["errs"] == 0 for x in rows)
+    assert r.stdout.count("counters: HBM-side") == len(rows)
+    by = {(x["ord"], x["schedule"]): x for x in rows}
+    for x in rows:
+        assert x["hbm_bytes"] > 4.0 * x["n"] * x["k"] and 0 < x["l2_hit"] < 1 and x["u_measured"] > 1, x
+    # the community schedule is the one that keeps B in the L2s: fewer bytes and a higher measured reuse than natural order
+    assert by[("OVO", "cluster")]["hbm_bytes"] < by[("OVO", "natural")]["hbm_bytes"]
+    assert by[("OVO", "cluster")]["u_measured"] > by[("OVO", "natural")]["u_measured"]
+    plain = subprocess.run([exe, os.path.join(GOLDEN, "a_mat.csv"), "8", "--json"], capture_output=True, text=True, timeout=300)
+    assert plain.returncode == 0 and "counters:" not in plain.stdout
+    assert all(json.loads(ln)["hbm_bytes"] == -1 for ln in plain.stdout.splitlines() if ln.startswith("{"))

@@ -17,7 +17,7 @@ rnd = os.environ.get("FLEX_ROUND", "r03")
 summ = json.load(open(os.path.join(out, "summary.json")))
 main = max((n for n in summ if n.startswith("spmm_") and "FETCH_SIZE" in summ[n]), key=lambda n: summ[n].get("avg_us", 0) * summ[n].get("calls", 1))
 d = summ[main]
-traffic = int(2 * d["FETCH_SIZE"] * 1e3 + d["WRITE_SIZE"] * 1e3)  # KB -> B; FETCH_SIZE doubled (gfx950: 128-B requests tallied at 64 B)
+traffic = int(2 * d["FETCH_SIZE"] * 1024 + d["WRITE_SIZE"] * 1024)  # KiB -> B; FETCH_SIZE doubled (gfx950: 128-B requests tallied at 64 B)
 tag = f"{rnd}_{workload}_k{k}"
 shutil.copy(os.path.join(out, "summary.json"), os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.json"))
 for f in glob.glob(os.path.join(out, "kt", "*", "*_kernel_stats.csv")):

@@ -27,7 +27,7 @@ for i, p in enumerate(pts):
     if g.get("TCC_HIT_sum") is not None:
         row["l2_hit"] = round(g["TCC_HIT_sum"] / (g["TCC_HIT_sum"] + g["TCC_MISS_sum"]), 3)
     if g.get("FETCH_SIZE") is not None and g.get("WRITE_SIZE") is not None:
-        row["traffic_MB"] = round((2 * g["FETCH_SIZE"] + g["WRITE_SIZE"]) / 1e3, 1)  # KB; FETCH doubled (gfx950)
+        row["traffic_MB"] = round((2 * g["FETCH_SIZE"] + g["WRITE_SIZE"]) * 1024 / 1e6, 1)  # KiB; FETCH doubled (gfx950)
         row["traffic_over_alg"] = round(row["traffic_MB"] / p["b_alg_MB"], 2)
     out.append(row)
     print(json.dumps(row))
