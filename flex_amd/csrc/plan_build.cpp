@@ -124,6 +124,7 @@ class PlanBuilder {
     // knobs
     uint32_t wave_nnz = 0, row_cost = 16, long_row = 0, piece_len = 0, seg_min = 4, pshift = 0;
     bool two_d = false;
+    bool xcd_dealt = false;  // tuning.xcd_slices = 3: stretches of the schedule dealt to the XCDs in turn (build_chunk_table)
     // pieces
     std::vector<Piece> pieces;
     std::vector<uint32_t> row_first_piece;  // [m+1] pieces of schedule position i
@@ -292,7 +293,8 @@ class PlanBuilder {
         const long remap_env = tn.xcd_slices;
         // A reordered loader planned as given says so itself: FLEX_PLAN_XCD_INTERLEAVE.
         const bool interleave = order == FLEX_ORDER_RCM || order == FLEX_ORDER_GORDER || (flags & FLEX_PLAN_XCD_INTERLEAVE) != 0;
-        p->xcd_remap = remap_env == 1 || (remap_env != 2 && !interleave);
+        p->xcd_remap = remap_env == 1 || remap_env == 3 || (remap_env != 2 && !interleave);
+        xcd_dealt = remap_env == 3;
         p->lds_extra = static_cast<unsigned>(std::max(0, tn.lds_extra)) & ~15u;
         // The record stream is read once per column tile.  Non-temporal loads keep it from displacing B rows in the L2s and
         // the Infinity Cache, but they also come back slower and sit on the header -> records -> gathers chain of every chunk.
@@ -348,7 +350,7 @@ class PlanBuilder {
         u.long_row = static_cast<int32_t>(long_row);
         u.piece_records = static_cast<int32_t>(piece_len);
         u.row_cost = static_cast<int32_t>(row_cost);
-        u.xcd_slices = p->xcd_remap ? 1 : 2;
+        u.xcd_slices = xcd_dealt ? 3 : p->xcd_remap ? 1 : 2;
         u.rec_nt = p->rec_nt ? 1 : 2;
         u.tile_group = p->tile_group ? static_cast<int32_t>(p->tile_group) : 1;
         u.unroll = p->unroll;
@@ -639,7 +641,26 @@ class PlanBuilder {
         };
         std::vector<uint4> chunk;
         p->tuning.xcd_balance = tn.xcd_balance == 2 ? 2 : 1;
-        if (two_d || (p->xcd_remap && n_real >= 8u * kXcds * kWavesPerBlock && tn.xcd_balance != 2)) {
+        if (xcd_dealt && !two_d && n_real >= 8u * kXcds * kWavesPerBlock) {
+            // Stretches of the schedule dealt to the XCDs in turn: XCD x walks stretches x, x + 8, x + 16, ...  Each XCD still has a
+            // stretch (a community, or a part of one) to itself -- its L2 keeps what the stretch reuses -- while the eight of them
+            // are on ADJACENT stretches at any time, so what neighbouring stretches share (the near ring of a community order) is
+            // fetched by one XCD and found in the Infinity Cache by the others.  Chunks carry about the same number of records each,
+            // so dealing by count balances the slices to within a stretch.
+            const uint32_t per = static_cast<uint32_t>(pick(tn.xcd_stretch, 256)) * kWavesPerBlock;
+            p->tuning.xcd_stretch = static_cast<int32_t>(per / kWavesPerBlock);
+            const uint32_t n_st = (n_real + per - 1) / per;
+            uint32_t len[kXcds] = {};
+            for (uint32_t s = 0; s < n_st; ++s) len[s % kXcds] += std::min(per, n_real - s * per);
+            uint32_t longest = *std::max_element(len, len + kXcds);
+            longest = (longest + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock;
+            chunk.assign(static_cast<size_t>(longest) * kXcds, make_uint4(0u, 0u, 0u, 0u));
+            uint32_t at[kXcds] = {};
+            for (uint32_t s = 0; s < n_st; ++s) {
+                const uint32_t x = s % kXcds, c0 = s * per, c1 = std::min(n_real, c0 + per);
+                for (uint32_t c = c0; c < c1; ++c) chunk[static_cast<size_t>(x) * longest + at[x]++] = header(c);
+            }
+        } else if (two_d || (p->xcd_remap && n_real >= 8u * kXcds * kWavesPerBlock && tn.xcd_balance != 2)) {
             uint32_t cut[kXcds + 1];
             cut[0] = 0;
             cut[kXcds] = n_real;

@@ -129,7 +129,9 @@ typedef struct flex_plan_tuning {
     int32_t long_row;        /* rows longer than this are cut into pieces (chunk_records) */
     int32_t piece_records;   /* ... of about this many records (chunk_records) */
     int32_t row_cost;        /* records a row boundary counts for when chunks are cut (16) */
-    int32_t xcd_slices;      /* 1: every XCD walks one contiguous slice of the schedule; 2: round-robin (rule: 1 except RCM / Gorder) */
+    int32_t xcd_slices;      /* 1: every XCD walks one contiguous slice of the schedule; 2: round-robin (rule: 1 except RCM / Gorder);
+                                3: stretches of xcd_stretch workgroups dealt to the XCDs in turn (the eight XCDs walk ADJACENT stretches of the
+                                schedule at any time, each still on its own stretch) */
     int32_t xcd_balance;     /* 2: slices cut by chunk count instead of by cost */
     int32_t chunk_cost, task_cost; /* cost model of the slice balancing (16, 2) */
     int32_t split_rows;      /* how the pieces of a split row are summed: 2 = by spmm_fixup_kernel after the launch (the default: it
@@ -157,7 +159,8 @@ typedef struct flex_plan_tuning {
     int32_t tile_group;       /* multi-tile launches: workgroups per group -- every XCD's slice of the schedule is walked group by group, all
                                  column tiles of a group back to back, so that a group's records are re-read from the Infinity Cache rather
                                  than from HBM (0 = rule; 1 = off: one pass over the whole schedule per tile) */
-    int32_t reserved[9];     /* zero */
+    int32_t xcd_stretch;     /* xcd_slices = 3: workgroups (4 chunks each) per stretch (256) */
+    int32_t reserved[8];     /* zero */
 } flex_plan_tuning;
 
 typedef struct flex_plan_desc {

@@ -133,12 +133,19 @@ def test_xcd_slices_are_a_rule_per_ordering_and_a_flag_for_reordered_loaders(sim
         c, s = shape(order=order)
         assert s % 8 == 0 and s >= c
     for order in (flex_amd.FLEX_ORDER_RCM, flex_amd.FLEX_ORDER_GORDER):
-        c, s = shape(order=order)
-        assert s == c
-    c, s = shape(vo_mp=vo)
-    assert s % 8 == 0 and s > c  # a reordered loader planned as given: slices, unless it asks otherwise
+        cr, s = shape(order=order)
+        assert s == cr
+    cv, s = shape(vo_mp=vo)
+    assert s % 8 == 0 and s > cv  # a reordered loader planned as given: slices, unless it asks otherwise
     c2, s2 = shape(vo_mp=vo, order=flex_amd.FLEX_PLAN_XCD_INTERLEAVE)
-    assert s2 == c2 == c
+    assert s2 == c2 == cv
+    # stretches of the schedule dealt to the XCDs in turn (tuning.xcd_slices = 3): still eight padded slices, every chunk once
+    c, _ = shape(order=flex_amd.FLEX_ORDER_CLUSTER)
+    for stretch in (1, 7, 64, 100000):
+        p = flex_amd.Plan(a, 128, order=flex_amd.FLEX_ORDER_CLUSTER, tuning={"xcd_slices": 3, "xcd_stretch": stretch})
+        p.self_check()
+        i, t = p.info(), p.tuning()
+        assert i["n_chunks"] == c and i["n_slots"] % 8 == 0 and i["n_slots"] >= c and t["xcd_slices"] == 3 and t["xcd_stretch"] == stretch
     with pytest.raises(flex_amd.FlexError):
         flex_amd.Plan(a, 128, order=0x4000)  # unknown flag bits are refused
 

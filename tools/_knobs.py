@@ -11,7 +11,7 @@ from flex_amd import binding
 
 ENV_TO_KNOB = {
     "FLEX_LANES": "lanes_per_nz", "FLEX_WAVE_NNZ": "chunk_records", "FLEX_LONG_ROW": "long_row", "FLEX_PIECE": "piece_records",
-    "FLEX_ROW_COST": "row_cost", "FLEX_XCD_REMAP": "xcd_slices", "FLEX_XCD_BALANCE": "xcd_balance", "FLEX_CHUNK_COST": "chunk_cost",
+    "FLEX_ROW_COST": "row_cost", "FLEX_XCD_REMAP": "xcd_slices", "FLEX_XCD_BALANCE": "xcd_balance", "FLEX_XCD_STRETCH": "xcd_stretch", "FLEX_CHUNK_COST": "chunk_cost",
     "FLEX_TASK_COST": "task_cost", "FLEX_FUSED_FIXUP": "split_rows", "FLEX_REC_NT": "rec_nt", "FLEX_U": "unroll", "FLEX_2D": "two_d",
     "FLEX_PANEL_KB": "panel_kb", "FLEX_SEG_MIN": "seg_min", "FLEX_MFMA": "mfma", "FLEX_MFMA_FILL": "mfma_fill_pct",
     "FLEX_LDS_EXTRA": "lds_extra", "FLEX_HOST_THREADS": "host_threads", "FLEX_CLUSTER_BATCH": "cluster_batch",

@@ -32,7 +32,8 @@ KNOBS = {
     "FLEX_FUSED_FIXUP": [None, None, "1", "2"],  # 1 = in-launch (opt-in since ABI 3), 2 = two launches (default)
     "FLEX_REC_NT": [None, "1", "2"],
     "FLEX_U": [None, None, "8"],
-    "FLEX_XCD_REMAP": [None, "1", "2"],
+    "FLEX_XCD_REMAP": [None, "1", "2", "3"],
+    "FLEX_XCD_STRETCH": [None, "1", "5", "64"],
     "FLEX_XCD_BALANCE": [None, None, "2"],
     "FLEX_LDS_EXTRA": [None, None, "16384"],
     "FLEX_HOST_THREADS": [None, "1", "3", "16"],
