@@ -586,14 +586,15 @@ def vendor_baseline(a, k, B, C):
 
 
 def cpu_baseline(a, k, B):
-    """The reference's CPU SpMM arithmetic (oracle port of aspt/sspmm_128.cu:1415-1422) timed on this
-    host on a bounded sample of the same workload: the first rows holding <= ~3e9 flops."""
+    """The reference's CPU SpMM arithmetic (oracle port of aspt/sspmm_128.cu:1415-1422) timed on this host.  The threaded leg runs
+    the WHOLE workload -- every row of the same CSR and B -- whenever that is predicted to fit ~10 s (the Amazon shape at k=128
+    takes 2-3 s on 16 threads), else the first rows holding ~1e10 flops; the single-thread leg always runs on that bounded sample."""
     import oracle
     host_cores = os.cpu_count() or 1
     # threads actually used by the multi-threaded leg: the share of the host one GPU's job is entitled to on the pool
     # (16 of the box's cores), never more than the process may run on
     cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cores, 16)
-    budget = 1.0e10 / (2.0 * k)  # nonzeros: ~20 core-seconds of the scalar loop in all (3 threaded runs + 1 single-thread run)
+    budget = 1.0e10 / (2.0 * k)  # nonzeros of the bounded sample
     rp = a.rowPtr.astype(np.int64)
     rows = int(np.searchsorted(rp, budget, side="right")) - 1 if a.nnz > budget else a.m
     rows = max(rows, 1)
@@ -608,9 +609,19 @@ def cpu_baseline(a, k, B):
     t0 = time.perf_counter()
     oracle.spmm(rp_s, a.col[:nnz], a.vals[:nnz], Bh, nthreads=1)
     best1 = time.perf_counter() - t0
-    return {"value": round(2.0 * nnz * k / bestN / 1e9, 3), "unit": "GFLOPS", "cores": cores, "host_cores": host_cores, "kind": "port",
-            "sample": f"first {rows} rows ({nnz} nnz) of the same graph and B, best of 3",
-            "single_thread_value": round(2.0 * nnz * k / best1 / 1e9, 3)}
+    value, sample = 2.0 * nnz * k / bestN / 1e9, f"first {rows} rows ({nnz} nnz) of the same graph and B, best of 3"
+    if rows < a.m and bestN * a.nnz / max(nnz, 1) <= 5.0:  # the whole job, twice, within ~10 s
+        full = 1e30
+        for i in range(2):
+            t0 = time.perf_counter()
+            oracle.spmm(a.rowPtr, a.col, a.vals, Bh, nthreads=cores)
+            full = min(full, time.perf_counter() - t0)
+        value, sample = 2.0 * a.nnz * k / full / 1e9, f"the whole workload: all {a.m} rows ({a.nnz} nnz) of the same graph and B, best of 2 ({full:.2f} s)"
+    elif rows >= a.m:
+        sample = f"the whole workload: all {a.m} rows ({a.nnz} nnz) of the same graph and B, best of 3"
+    return {"value": round(value, 3), "unit": "GFLOPS", "cores": cores, "host_cores": host_cores, "kind": "port", "sample": sample,
+            "single_thread_value": round(2.0 * nnz * k / best1 / 1e9, 3),
+            "single_thread_sample": f"first {rows} rows ({nnz} nnz), one run"}
 
 
 if __name__ == "__main__":
