@@ -279,7 +279,13 @@ def main():
             counted = live.traffic(launches, device=local_rank, sync=torch.cuda.synchronize, launches=n_cnt)
             l2 = live.count(launches, live.L2_PASS, device=local_rank, sync=torch.cuda.synchronize)
             counted["l2_hit_rate"] = l2["TCC_HIT_sum"] / max(1.0, l2["TCC_HIT_sum"] + l2["TCC_MISS_sum"])
+            counted["l2_requests"] = l2["TCC_REQ_sum"] / n_cnt
             counted["launches_per_pass"] = n_cnt
+            try:  # the instruction mix is a bonus: a card that refuses the SQ pass still reports the memory side
+                sq = live.count(launches, live.SQ_PASS, device=local_rank, sync=torch.cuda.synchronize)
+                counted["sq"] = {name: v / n_cnt for name, v in sq.items()}
+            except Exception as e:  # noqa: BLE001
+                print(f"bench.py: SQ pass refused ({e})", file=sys.stderr, flush=True)
         except Exception as e:  # noqa: BLE001
             print(f"bench.py: in-run counters failed ({type(e).__name__}: {e}); roofline.traffic falls back to profiles/pmc_traffic.json",
                   file=sys.stderr, flush=True)
@@ -356,6 +362,16 @@ def main():
             out["roofline"]["traffic_write_bytes"] = int(counted["write_bytes"])
             out["roofline"]["traffic_over_algorithmic"] = round(counted["traffic_bytes"] / b_alg, 2)
             out["roofline"]["l2_hit_rate"] = round(counted["l2_hit_rate"], 4)
+            # ≙ the reference's measured L1<->L2 bytes over its estimate ("L2/", flex.cu:5279-5330): requests the L2s received x 128 B,
+            # next to what the schedule asks of them (B gathers + the record stream once per column tile + C)
+            out["roofline"]["l1_l2_bytes_measured"] = int(counted["l2_requests"] * live.L2_REQUEST_BYTES)
+            ktiles = -(-k // (4 * g_lanes))
+            est = gather_demand + 8.0 * float(info.get("n_records", shard_nnz)) * ktiles + 4.0 * shard_rows * k
+            out["roofline"]["l1_l2_bytes_over_estimate"] = round(counted["l2_requests"] * live.L2_REQUEST_BYTES / max(est, 1.0), 3)
+            if "sq" in counted:  # wave instructions per 64 multiply-adds (one wave-wide FMA's worth), ≙ "Per Mult / Num Insns" (flex.cu:5350-5420)
+                per = shard_nnz * float(k) / 64.0
+                out["roofline"]["wave_insns_per_64_fma"] = {n_[len("SQ_INSTS_"):].lower(): round(v / per, 3) for n_, v in counted["sq"].items() if n_ != "SQ_WAVES"}
+                out["roofline"]["waves_per_launch"] = int(counted["sq"]["SQ_WAVES"])
             b_fetched = counted["read_bytes"] - 8.0 * shard_nnz - 4.0 * (shard_rows + 1)
             # null when the L2s served (nearly) everything: a graph whose A and B stay resident in 32 MiB of L2 fetches no B at all
             out["roofline"]["u_measured"] = round(4.0 * shard_nnz * k / b_fetched, 3) if b_fetched > 0.01 * 4.0 * a.n * k else None

@@ -1,6 +1,7 @@
 // DataLoader.cpp (host mirror) -- see DataLoader.h.  Behaviour follows DataLoader.cu of the
 // reference (line numbers cited per function); the code is new and sits on the engine's C ABI.
 #include "DataLoader.h"
+#include "lazy_lib.h"
 
 #include <cassert>
 #include <cstdlib>
@@ -122,7 +123,7 @@ void DataLoader::freeAll() {
         hip_freez(gpuW);
         hip_freez(gpuRef1);
         hip_freez(gpuRef2);
-        if (axw) flex_axw_destroy(axw);
+        if (axw) FLEX_AXW(flex_axw_destroy)(axw);
         axw = nullptr;
     } catch (...) {
     }

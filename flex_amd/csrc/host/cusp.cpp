@@ -9,16 +9,17 @@
 #include <iostream>
 
 #include "flex.h"
+#include "lazy_lib.h"
 
 void DataLoader::axw_alloc() {  // ≙ the AXW part of cuda_alloc_cpy, DataLoader.cu:169-176 (+ cpuRef1/2, DataLoader.cuh:47-48)
     if (axw) return;
     const flex_csr a = csr_view();
-    FLEX_CHECK(flex_axw_create(&axw, &a, static_cast<int>(dim), static_cast<int>(c), 0, FLEX_ORDER_CLUSTER));
+    FLEX_CHECK(FLEX_AXW(flex_axw_create)(&axw, &a, static_cast<int>(dim), static_cast<int>(c), 0, FLEX_ORDER_CLUSTER));
     cpuW.resize(dim * c);
     for (float &w : cpuW) w = static_cast<float>(std::rand()) / static_cast<float>(RAND_MAX);  // DataLoader.cu:172
     HIP_CHECK(hipMalloc(&gpuW, sizeof(float) * dim * c));
     HIP_CHECK(hipMemcpy(gpuW, cpuW.data(), sizeof(float) * dim * c, hipMemcpyHostToDevice));
-    const size_t ld = static_cast<size_t>(flex_axw_ld(static_cast<int>(c)));
+    const size_t ld = static_cast<size_t>(FLEX_AXW(flex_axw_ld)(static_cast<int>(c)));
     HIP_CHECK(hipMalloc(&gpuRef1, sizeof(float) * n * ld));
     HIP_CHECK(hipMalloc(&gpuRef2, sizeof(float) * n * ld));
     cpuRef1.resize(n * ld);
@@ -26,7 +27,7 @@ void DataLoader::axw_alloc() {  // ≙ the AXW part of cuda_alloc_cpy, DataLoade
 }
 
 bool DataLoader::compare() {  // DataLoader.cu:859-869, with a relative bound in place of the absolute 0.1
-    const size_t ld = static_cast<size_t>(flex_axw_ld(static_cast<int>(c)));
+    const size_t ld = static_cast<size_t>(FLEX_AXW(flex_axw_ld)(static_cast<int>(c)));
     for (size_t i = 0; i < m; ++i)
         for (size_t j = 0; j < c; ++j) {
             const float a = cpuRef1[i * ld + j], b = cpuRef2[i * ld + j];
@@ -44,7 +45,7 @@ namespace {
 
 int run_order(DataLoader &input, Metrics &metric, int order, float *gpuRef, std::vector<float> &cpuRef) {
     float gemm_ms = 0.f, spmm_ms = 0.f;
-    FLEX_CHECK(flex_axw_run(input.axw, order, input.gpuX, input.gpuW, gpuRef, nullptr, &gemm_ms, &spmm_ms));
+    FLEX_CHECK(FLEX_AXW(flex_axw_run)(input.axw, order, input.gpuX, input.gpuW, gpuRef, nullptr, &gemm_ms, &spmm_ms));
     metric.t += gemm_ms + spmm_ms;
     metric.spmm_t += spmm_ms;
     metric.gemm_t += gemm_ms;

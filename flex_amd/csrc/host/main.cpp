@@ -1,5 +1,6 @@
 // main.cpp (host mirror) -- ≙ main.cu:7-83 (the non-AXW path): flex <csv|synth:name[*scale]> <k>
 // [--iters N] [--warmup N] [--json] [--stats] [--perm-cache DIR] [--csv FILE] [--stats-log FILE] [--no-vendor] [--gpus N] [--axw] [--debug-values] [--counters]
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -27,6 +28,7 @@ int main(int argc, char *argv[]) {
         else if (!std::strcmp(argv[i], "--warmup") && i + 1 < argc) run_options().warmup = std::atoi(argv[++i]);
         else { std::fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
     }
+    std::setvbuf(stdout, nullptr, _IOLBF, 0);  // a table row is visible as soon as it is measured, also in a log file
     try {
         if (run_options().counters) counters_attach();  // before the loader makes the first HIP call
         DataLoader data(argv[1], std::atoi(argv[2]));

@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include <cfloat>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -12,6 +13,7 @@
 #include "../../../include/flex_mg.h"
 #include "../../../include/flex_vendor.h"
 #include "flex.h"
+#include "lazy_lib.h"
 
 RunOptions &run_options() {
     static RunOptions o;
@@ -30,6 +32,7 @@ struct CountersLib {
 
 // one pass around `launches` launches of `mat`; returns the per-launch sums (false + message on stderr when the profiler refuses)
 bool counted(Mat &mat, int launches, const char *const *names, int n, double *out) {
+    if (std::getenv("FLEX_COUNTERS_DEBUG")) std::fprintf(stderr, "flex --counters: pass %s (+%d)\n", names[0], n - 1);
     HIP_CHECK(hipDeviceSynchronize());
     if (g_counters.begin(0, names, n) != 0) {
         std::fprintf(stderr, "flex --counters: %s\n", g_counters.error());
@@ -66,17 +69,18 @@ void cuSpmm(DataLoader &input, Perfs &perfRes) {
     HIP_CHECK(hipEventCreate(&e3));
     flex_vendor *h = nullptr;
     HIP_CHECK(hipEventRecord(e0, nullptr));
-    const int rc = flex_vendor_spmm_create(&h, static_cast<int32_t>(input.m), static_cast<int32_t>(input.n),
+    const int rc = FLEX_VENDOR(flex_vendor_spmm_create)(&h, static_cast<int32_t>(input.m), static_cast<int32_t>(input.n),
                                            static_cast<int64_t>(input.nnz), input.rowPtr_dev, input.col_dev,
                                            input.vals_dev, static_cast<int>(input.dim), input.gpuX, input.gpuC);
     if (rc) {  // the reference's CHECK_CUSPARSE only prints (common.h:81-90); a missing gold is fatal here
-        std::printf("hipSPARSE API failed: code %d status %d\n", rc, flex_vendor_last_status());
+        std::printf("hipSPARSE API failed: code %d status %d\n", rc, FLEX_VENDOR(flex_vendor_last_status)());
         throw std::runtime_error("hipSPARSE SpMM setup failed");
     }
     HIP_CHECK(hipEventRecord(e1, nullptr));
-    for (int i = 0; i < 5; ++i) flex_vendor_spmm_run(h, nullptr);  // warm-up, flex.cu:5766-5773
+    const auto vendor_run = FLEX_VENDOR(flex_vendor_spmm_run);  // resolved once: the timed loop calls through the pointer
+    for (int i = 0; i < 5; ++i) vendor_run(h, nullptr);  // warm-up, flex.cu:5766-5773
     HIP_CHECK(hipEventRecord(e2, nullptr));
-    for (int i = 0; i < 10; ++i) flex_vendor_spmm_run(h, nullptr);
+    for (int i = 0; i < 10; ++i) vendor_run(h, nullptr);
     HIP_CHECK(hipEventRecord(e3, nullptr));
     HIP_CHECK(hipEventSynchronize(e3));
     float setup_ms = 0, proc_ms = 0;
@@ -85,7 +89,7 @@ void cuSpmm(DataLoader &input, Perfs &perfRes) {
     perfRes.cuSpmmSetup = setup_ms * 1e3f;
     perfRes.cuSpmmProcessing = proc_ms * 1e3f / 10;  // microseconds per SpMM
     perfRes.cuSpmm_time = perfRes.cuSpmmSetup + perfRes.cuSpmmProcessing;
-    flex_vendor_spmm_destroy(h);
+    FLEX_VENDOR(flex_vendor_spmm_destroy)(h);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     (void)hipEventDestroy(e2);
@@ -140,6 +144,9 @@ struct Row {
     // (2 x FETCH_SIZE + WRITE_SIZE in KiB: the gfx950 correction of MI355X_MICROARCH "HBM"), L2 hit rate, and
     // u = B bytes the nonzeros ask for / bytes the L2 fetched beyond A's; all < 0 when not measured
     double hbm_bytes = -1, l2_hit = -1, u_meas = -1;
+    // ≙ "L2/" (measured L1<->L2 bytes, here requests x 128 B) and "Per Mult / Num Insns" (flex.cu:5279-5330, 5350-5420):
+    // wave instructions per 64 multiply-adds; < 0 when not measured
+    double l2_bytes = -1, vmem_rd = -1, valu = -1, lds = -1, salu = -1;
 };
 
 void bench_one(DataLoader &dl, unsigned schedule, const char *sched_name, const DataLoader &gold_src, float *h_res,
@@ -177,11 +184,17 @@ void bench_one(DataLoader &dl, unsigned schedule, const char *sched_name, const 
     if (!gold_src.h_ref_c.empty()) errs = resCheck(gold_src.h_ref_c.data(), h_res, mat, perfRes, &max_err);
     const double flops = 2.0 * dl.nnz * dl.dim;
     const double balg = (double(dl.n) + 1 + 2.0 * dl.nnz + 2.0 * dl.n * dl.dim) * 4;  // flex.cu:4672, 5795
-    double hbm_bytes = -1, l2_hit = -1, u_meas = -1;
+    double hbm_bytes = -1, l2_hit = -1, u_meas = -1, l2_bytes = -1, vmem_rd = -1, valu = -1, lds = -1, salu = -1;
     if (o.counters) {  // after the timed launches: three passes (the TCC block cannot hold FETCH_SIZE and WRITE_SIZE at once)
-        const char *fetch[] = {"FETCH_SIZE"}, *write[] = {"WRITE_SIZE"}, *l2[] = {"TCC_HIT_sum", "TCC_MISS_sum"};
-        double f = 0, w = 0, hm[2] = {0, 0};
-        if (counted(mat, o.iters, fetch, 1, &f) && counted(mat, o.iters, write, 1, &w) && counted(mat, o.iters, l2, 2, hm)) {
+        const char *fetch[] = {"FETCH_SIZE"}, *write[] = {"WRITE_SIZE"}, *l2[] = {"TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"};
+        const char *sq[] = {"SQ_INSTS_VMEM_RD", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU"};
+        double f = 0, w = 0, hm[3] = {0, 0, 0}, in[4] = {0, 0, 0, 0};
+        if (counted(mat, o.iters, fetch, 1, &f) && counted(mat, o.iters, write, 1, &w) && counted(mat, o.iters, l2, 3, hm)) {
+            l2_bytes = 128.0 * hm[2];
+            if (counted(mat, o.iters, sq, 4, in)) {
+                const double per = double(dl.nnz) * dl.dim / 64.0;
+                vmem_rd = in[0] / per, valu = in[1] / per, lds = in[2] / per, salu = in[3] / per;
+            }
             const double rd = 2.0 * 1024.0 * f, a_bytes = 8.0 * dl.nnz + 4.0 * (dl.n + 1);
             hbm_bytes = rd + 1024.0 * w;
             l2_hit = hm[0] / std::max(1.0, hm[0] + hm[1]);
@@ -191,7 +204,7 @@ void bench_one(DataLoader &dl, unsigned schedule, const char *sched_name, const 
     flex_imbalance imb{};
     if (flex_plan_measure_imbalance(mat.plan, mat.mat_b_dev, mat.mat_c_dev, nullptr, &imb) != FLEX_OK) imb = flex_imbalance{};  // odd k: no stamped twin
     rows.push_back({dl.vertex_order_abbr, sched_name, t_us, flops / t_us * 1e-3, balg / t_us * 1e-3,
-                    mat.info().plan_ms, max_err, errs, mat.info(), mat.stats(), imb, hbm_bytes, l2_hit, u_meas});
+                    mat.info().plan_ms, max_err, errs, mat.info(), mat.stats(), imb, hbm_bytes, l2_hit, u_meas, l2_bytes, vmem_rd, valu, lds, salu});
     perfRes.flex_spmm_time.push_back(static_cast<float>(t_us * 1e-3));
     mat.alpha_freeMatGPU();
 }
@@ -271,17 +284,22 @@ void run(DataLoader &input_vo) {
             std::printf("     counters: HBM-side %.1f MB/launch = %.2fx Balg, %.0f GB/s (%.1f %% of 8 TB/s), L2 hit %.3f, u %.2f\n",
                         r.hbm_bytes * 1e-6, r.hbm_bytes / (r.balg_gbs * r.t_us * 1e3), r.hbm_bytes / r.t_us * 1e-3,
                         r.hbm_bytes / r.t_us * 1e-3 / 8000.0 * 100, r.l2_hit, r.u_meas);
+        if (r.l2_bytes >= 0)  // ≙ the L1<->L2 bytes and "Per Mult / Num Insns" columns (flex.cu:5279-5330, 5350-5420)
+            std::printf("               L1<->L2 %.1f MB/launch (%.0f GB/s); wave insns per 64 FMAs: vmem_rd %.2f valu %.2f lds %.2f salu %.2f\n",
+                        r.l2_bytes * 1e-6, r.l2_bytes / r.t_us * 1e-3, r.vmem_rd, r.valu, r.lds, r.salu);
         if (o.json)
             std::printf("{\"graph\":\"%s\",\"n\":%zu,\"nnz\":%zu,\"k\":%zu,\"ord\":\"%s\",\"schedule\":\"%s\",\"t_us\":%.3f,"
                         "\"gflops\":%.2f,\"balg_gbs\":%.2f,\"max_err\":%.3g,\"errs\":%d,\"vendor_us\":%.3f,\"b_re1\":%.3f,\"b_re2\":%.3f,"
                         "\"chunk_imb_pct\":%.1f,\"xcd_imb_pct\":%.2f,\"cu_imb_pct\":%.2f,\"cu_end_spread_pct\":%.2f,\"xcd_busy_imb_pct\":%.2f,"
                         "\"cus_seen\":%d,\"plan_ms\":%.2f,\"tpre_over_telap\":%.1f,\"mfma_tiles\":%lld,\"tile_nnz_pct_25\":%.2f,"
-                        "\"hbm_bytes\":%.0f,\"l2_hit\":%.4f,\"u_measured\":%.3f}\n",
+                        "\"hbm_bytes\":%.0f,\"l2_hit\":%.4f,\"u_measured\":%.3f,\"l1_l2_bytes\":%.0f,\"vmem_rd_per_64fma\":%.3f,"
+                        "\"valu_per_64fma\":%.3f,\"lds_per_64fma\":%.3f}\n",
                         input_vo.graph_name.c_str(), input_vo.n, input_vo.nnz, input_vo.dim, r.ord.c_str(),
                         r.sched.c_str(), r.t_us, r.gflops, r.balg_gbs, r.max_err, r.errs, perfRes.cuSpmmProcessing,
                         r.stats.reuse_wave, r.stats.reuse_xcd, r.stats.chunk_imb_pct, r.stats.xcd_imb_pct, r.imb.cu_busy_imb_pct,
                         r.imb.cu_end_spread_pct, r.imb.xcd_busy_imb_pct, r.imb.cus_seen, r.plan_ms, r.plan_ms * 1e3 / r.t_us,
-                        static_cast<long long>(r.stats.mfma_tiles), r.stats.tile_nnz_pct_25, r.hbm_bytes, r.l2_hit, r.u_meas);
+                        static_cast<long long>(r.stats.mfma_tiles), r.stats.tile_nnz_pct_25, r.hbm_bytes, r.l2_hit, r.u_meas, r.l2_bytes,
+                        r.vmem_rd, r.valu, r.lds);
     }
     int mg_errs = 0;
     if (o.gpus > 0) {  // row-sharded over several GPUs (new; the reference is single-GPU, flex.cu:4137)
@@ -291,19 +309,19 @@ void run(DataLoader &input_vo) {
         // and say which layer failed: FLEX_CHECK throws, main() turns that into exit code 1; the RCCL result is printed first
         auto mg_check = [&](int st, const char *what) {
             if (st == FLEX_OK) return;
-            std::printf("flex --gpus %d: %s failed: %s (rccl result %d, hip error %d: %s)\n", o.gpus, what, flex_strerror(st), flex_mg_last_rccl(),
+            std::printf("flex --gpus %d: %s failed: %s (rccl result %d, hip error %d: %s)\n", o.gpus, what, flex_strerror(st), FLEX_MG(flex_mg_last_rccl)(),
                         flex_last_hip_error(), flex_last_hip_error_string());
             std::fflush(stdout);
             FLEX_CHECK(st);
         };
-        mg_check(flex_mg_create(&mg, &a, static_cast<int>(input_vo.dim), o.gpus, nullptr, FLEX_ORDER_CLUSTER), "flex_mg_create");
+        mg_check(FLEX_MG(flex_mg_create)(&mg, &a, static_cast<int>(input_vo.dim), o.gpus, nullptr, FLEX_ORDER_CLUSTER), "flex_mg_create");
         double bcast_ms = 0, us = 0;
-        mg_check(flex_mg_set_B(mg, input_vo.cpuX.data(), &bcast_ms), "flex_mg_set_B (RCCL broadcast)");
-        FLEX_CHECK(flex_mg_time(mg, o.warmup, o.iters, &us));
-        FLEX_CHECK(flex_mg_get_C(mg, h_res.get()));
+        mg_check(FLEX_MG(flex_mg_set_B)(mg, input_vo.cpuX.data(), &bcast_ms), "flex_mg_set_B (RCCL broadcast)");
+        FLEX_CHECK(FLEX_MG(flex_mg_time)(mg, o.warmup, o.iters, &us));
+        FLEX_CHECK(FLEX_MG(flex_mg_get_C)(mg, h_res.get()));
         std::vector<int64_t> bounds(o.gpus + 1), snnz(o.gpus);
-        flex_mg_shard_info(mg, bounds.data(), snnz.data());
-        flex_mg_destroy(mg);
+        FLEX_MG(flex_mg_shard_info)(mg, bounds.data(), snnz.data());
+        FLEX_MG(flex_mg_destroy)(mg);
         double max_err = 0;
         if (!input_vo.h_ref_c.empty()) {
             Mat probe(input_vo, 0, 0);
