@@ -280,6 +280,7 @@ def main():
             l2 = live.count(launches, live.L2_PASS, device=local_rank, sync=torch.cuda.synchronize)
             counted["l2_hit_rate"] = l2["TCC_HIT_sum"] / max(1.0, l2["TCC_HIT_sum"] + l2["TCC_MISS_sum"])
             counted["l2_requests"] = l2["TCC_REQ_sum"] / n_cnt
+            counted["l2_reads"] = l2["TCC_READ_sum"] / n_cnt
             counted["launches_per_pass"] = n_cnt
             try:  # the instruction mix is a bonus: a card that refuses the SQ pass still reports the memory side
                 sq = live.count(launches, live.SQ_PASS, device=local_rank, sync=torch.cuda.synchronize)
@@ -368,6 +369,12 @@ def main():
             ktiles = -(-k // (4 * g_lanes))
             est = gather_demand + 8.0 * float(info.get("n_records", shard_nnz)) * ktiles + 4.0 * shard_rows * k
             out["roofline"]["l1_l2_bytes_over_estimate"] = round(counted["l2_requests"] * live.L2_REQUEST_BYTES / max(est, 1.0), 3)
+            # The reference's own `u` (flex.cu:5513-5528) is one level up: nD = bytes L1 reads from L2 per multiply-add = 4/u + (A's share),
+            # i.e. how often a B element that reached a CU is used there.  Here A's share is the record stream, re-read once per column tile.
+            n_madd = shard_nnz * float(k)
+            nd = counted["l2_reads"] * live.L2_REQUEST_BYTES / max(n_madd, 1.0)
+            out["roofline"]["nD_l1_from_l2_bytes_per_fma"] = round(nd, 3)
+            out["roofline"]["u_l1_measured"] = round(4.0 / max(nd - 8.0 * ktiles / k, 1e-9), 3)
             if "sq" in counted:  # wave instructions per 64 multiply-adds (one wave-wide FMA's worth), ≙ "Per Mult / Num Insns" (flex.cu:5350-5420)
                 per = shard_nnz * float(k) / 64.0
                 out["roofline"]["wave_insns_per_64_fma"] = {n_[len("SQ_INSTS_"):].lower(): round(v / per, 3) for n_, v in counted["sq"].items() if n_ != "SQ_WAVES"}
@@ -375,6 +382,7 @@ def main():
             b_fetched = counted["read_bytes"] - 8.0 * shard_nnz - 4.0 * (shard_rows + 1)
             # null when the L2s served (nearly) everything: a graph whose A and B stay resident in 32 MiB of L2 fetches no B at all
             out["roofline"]["u_measured"] = round(4.0 * shard_nnz * k / b_fetched, 3) if b_fetched > 0.01 * 4.0 * a.n * k else None
+            out["roofline"]["u_l2_measured"] = out["roofline"]["u_measured"]  # the same number under its level's name (L2 <- HBM side)
             out["roofline"]["traffic_rocprofv3_committed"] = _pmc_traffic(args, world)  # the offline figure for the same sources, or null
         if out["roofline"]["traffic"] is not None:
             out["roofline"]["model_fabric_ms"] = round(out["roofline"]["traffic"] / 6.3e12 * 1e3, 6)

@@ -18,7 +18,7 @@ FETCH_BYTES_PER_UNIT = 2 * 1024
 WRITE_BYTES_PER_UNIT = 1024
 # FETCH_SIZE takes 3 of the TCC block's 4 counter slots and WRITE_SIZE 2: one pass each
 TRAFFIC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",))
-L2_PASS = ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum")
+L2_PASS = ("TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "TCC_READ_sum")  # the TCC block's four slots
 L2_REQUEST_BYTES = 128  # a TCC request is one 128-byte line (amazon k=128: 1.09e9 requests per launch for 138 GB of gather demand)
 # wave-level instruction counts (≙ the reference's "Per Mult / Num Insns" columns, flex.cu:5350-5420): one SQ pass
 SQ_PASS = ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS", "SQ_INSTS_SMEM")

@@ -146,7 +146,7 @@ struct Row {
     double hbm_bytes = -1, l2_hit = -1, u_meas = -1;
     // ≙ "L2/" (measured L1<->L2 bytes, here requests x 128 B) and "Per Mult / Num Insns" (flex.cu:5279-5330, 5350-5420):
     // wave instructions per 64 multiply-adds; < 0 when not measured
-    double l2_bytes = -1, vmem_rd = -1, valu = -1, lds = -1, salu = -1;
+    double l2_bytes = -1, vmem_rd = -1, valu = -1, lds = -1, salu = -1, u_l1 = -1;
 };
 
 void bench_one(DataLoader &dl, unsigned schedule, const char *sched_name, const DataLoader &gold_src, float *h_res,
@@ -184,13 +184,19 @@ void bench_one(DataLoader &dl, unsigned schedule, const char *sched_name, const 
     if (!gold_src.h_ref_c.empty()) errs = resCheck(gold_src.h_ref_c.data(), h_res, mat, perfRes, &max_err);
     const double flops = 2.0 * dl.nnz * dl.dim;
     const double balg = (double(dl.n) + 1 + 2.0 * dl.nnz + 2.0 * dl.n * dl.dim) * 4;  // flex.cu:4672, 5795
-    double hbm_bytes = -1, l2_hit = -1, u_meas = -1, l2_bytes = -1, vmem_rd = -1, valu = -1, lds = -1, salu = -1;
+    double hbm_bytes = -1, l2_hit = -1, u_meas = -1, l2_bytes = -1, vmem_rd = -1, valu = -1, lds = -1, salu = -1, u_l1 = -1;
     if (o.counters) {  // after the timed launches: three passes (the TCC block cannot hold FETCH_SIZE and WRITE_SIZE at once)
-        const char *fetch[] = {"FETCH_SIZE"}, *write[] = {"WRITE_SIZE"}, *l2[] = {"TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum"};
+        const char *fetch[] = {"FETCH_SIZE"}, *write[] = {"WRITE_SIZE"}, *l2[] = {"TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "TCC_READ_sum"};
         const char *sq[] = {"SQ_INSTS_VMEM_RD", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU"};
-        double f = 0, w = 0, hm[3] = {0, 0, 0}, in[4] = {0, 0, 0, 0};
-        if (counted(mat, o.iters, fetch, 1, &f) && counted(mat, o.iters, write, 1, &w) && counted(mat, o.iters, l2, 3, hm)) {
+        double f = 0, w = 0, hm[4] = {0, 0, 0, 0}, in[4] = {0, 0, 0, 0};
+        if (counted(mat, o.iters, fetch, 1, &f) && counted(mat, o.iters, write, 1, &w) && counted(mat, o.iters, l2, 4, hm)) {
             l2_bytes = 128.0 * hm[2];
+            {   // the reference's own u (flex.cu:5513-5528): nD = bytes L1 reads from L2 per multiply-add = 4/u + A's share (here the
+                // record stream, once per column tile of 4 x lanes_per_nz columns)
+                const double ktiles = std::ceil(double(dl.dim) / (4.0 * std::max(1, mat.info().lanes_per_nz)));
+                const double nd = 128.0 * hm[3] / (double(dl.nnz) * dl.dim);
+                u_l1 = 4.0 / std::max(nd - 8.0 * ktiles / dl.dim, 1e-9);
+            }
             if (counted(mat, o.iters, sq, 4, in)) {
                 const double per = double(dl.nnz) * dl.dim / 64.0;
                 vmem_rd = in[0] / per, valu = in[1] / per, lds = in[2] / per, salu = in[3] / per;
@@ -204,7 +210,7 @@ void bench_one(DataLoader &dl, unsigned schedule, const char *sched_name, const 
     flex_imbalance imb{};
     if (flex_plan_measure_imbalance(mat.plan, mat.mat_b_dev, mat.mat_c_dev, nullptr, &imb) != FLEX_OK) imb = flex_imbalance{};  // odd k: no stamped twin
     rows.push_back({dl.vertex_order_abbr, sched_name, t_us, flops / t_us * 1e-3, balg / t_us * 1e-3,
-                    mat.info().plan_ms, max_err, errs, mat.info(), mat.stats(), imb, hbm_bytes, l2_hit, u_meas, l2_bytes, vmem_rd, valu, lds, salu});
+                    mat.info().plan_ms, max_err, errs, mat.info(), mat.stats(), imb, hbm_bytes, l2_hit, u_meas, l2_bytes, vmem_rd, valu, lds, salu, u_l1});
     perfRes.flex_spmm_time.push_back(static_cast<float>(t_us * 1e-3));
     mat.alpha_freeMatGPU();
 }
@@ -285,20 +291,20 @@ void run(DataLoader &input_vo) {
                         r.hbm_bytes * 1e-6, r.hbm_bytes / (r.balg_gbs * r.t_us * 1e3), r.hbm_bytes / r.t_us * 1e-3,
                         r.hbm_bytes / r.t_us * 1e-3 / 8000.0 * 100, r.l2_hit, r.u_meas);
         if (r.l2_bytes >= 0)  // ≙ the L1<->L2 bytes and "Per Mult / Num Insns" columns (flex.cu:5279-5330, 5350-5420)
-            std::printf("               L1<->L2 %.1f MB/launch (%.0f GB/s); wave insns per 64 FMAs: vmem_rd %.2f valu %.2f lds %.2f salu %.2f\n",
-                        r.l2_bytes * 1e-6, r.l2_bytes / r.t_us * 1e-3, r.vmem_rd, r.valu, r.lds, r.salu);
+            std::printf("               L1<->L2 %.1f MB/launch (%.0f GB/s), u at L1 %.2f; wave insns per 64 FMAs: vmem_rd %.2f valu %.2f lds %.2f salu %.2f\n",
+                        r.l2_bytes * 1e-6, r.l2_bytes / r.t_us * 1e-3, r.u_l1, r.vmem_rd, r.valu, r.lds, r.salu);
         if (o.json)
             std::printf("{\"graph\":\"%s\",\"n\":%zu,\"nnz\":%zu,\"k\":%zu,\"ord\":\"%s\",\"schedule\":\"%s\",\"t_us\":%.3f,"
                         "\"gflops\":%.2f,\"balg_gbs\":%.2f,\"max_err\":%.3g,\"errs\":%d,\"vendor_us\":%.3f,\"b_re1\":%.3f,\"b_re2\":%.3f,"
                         "\"chunk_imb_pct\":%.1f,\"xcd_imb_pct\":%.2f,\"cu_imb_pct\":%.2f,\"cu_end_spread_pct\":%.2f,\"xcd_busy_imb_pct\":%.2f,"
                         "\"cus_seen\":%d,\"plan_ms\":%.2f,\"tpre_over_telap\":%.1f,\"mfma_tiles\":%lld,\"tile_nnz_pct_25\":%.2f,"
-                        "\"hbm_bytes\":%.0f,\"l2_hit\":%.4f,\"u_measured\":%.3f,\"l1_l2_bytes\":%.0f,\"vmem_rd_per_64fma\":%.3f,"
+                        "\"hbm_bytes\":%.0f,\"l2_hit\":%.4f,\"u_measured\":%.3f,\"l1_l2_bytes\":%.0f,\"u_l1\":%.3f,\"vmem_rd_per_64fma\":%.3f,"
                         "\"valu_per_64fma\":%.3f,\"lds_per_64fma\":%.3f}\n",
                         input_vo.graph_name.c_str(), input_vo.n, input_vo.nnz, input_vo.dim, r.ord.c_str(),
                         r.sched.c_str(), r.t_us, r.gflops, r.balg_gbs, r.max_err, r.errs, perfRes.cuSpmmProcessing,
                         r.stats.reuse_wave, r.stats.reuse_xcd, r.stats.chunk_imb_pct, r.stats.xcd_imb_pct, r.imb.cu_busy_imb_pct,
                         r.imb.cu_end_spread_pct, r.imb.xcd_busy_imb_pct, r.imb.cus_seen, r.plan_ms, r.plan_ms * 1e3 / r.t_us,
-                        static_cast<long long>(r.stats.mfma_tiles), r.stats.tile_nnz_pct_25, r.hbm_bytes, r.l2_hit, r.u_meas, r.l2_bytes,
+                        static_cast<long long>(r.stats.mfma_tiles), r.stats.tile_nnz_pct_25, r.hbm_bytes, r.l2_hit, r.u_meas, r.l2_bytes, r.u_l1,
                         r.vmem_rd, r.valu, r.lds);
     }
     int mg_errs = 0;

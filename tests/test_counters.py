@@ -123,6 +123,9 @@ def test_cli_prints_measured_bytes_per_table_row():
         assert x["hbm_bytes"] > 4.0 * x["n"] * x["k"] and 0 < x["l2_hit"] < 1 and x["u_measured"] > 1, x
         # every nonzero's B segment crosses L1<->L2 at most once per request line; the wave-level mix has more VALU than memory instructions
         assert x["l1_l2_bytes"] >= x["hbm_bytes"] * 0.5 and 0 < x["vmem_rd_per_64fma"] < x["valu_per_64fma"], x
+        # the reference's own u (L1 <- L2 level, flex.cu:5513-5528): the flat kernel pulls every nonzero's B segment through the L2
+        # itself, so it sits near 1 whatever the ordering; the L2-level u above is where the orderings differ
+        assert 0.8 < x["u_l1"] < 2.0, x
     # the community schedule is the one that keeps B in the L2s: fewer bytes and a higher measured reuse than natural order
     assert by[("OVO", "cluster")]["hbm_bytes"] < by[("OVO", "natural")]["hbm_bytes"]
     assert by[("OVO", "cluster")]["u_measured"] > by[("OVO", "natural")]["u_measured"]
