@@ -4,7 +4,7 @@
 out=${1:-gpurun_out/bench_lines.jsonl}
 : > $out
 for k in 32 128; do  # the one real data file the reference ships, checked against the oracle
-  timeout -k 10 300 python bench.py --graph tests/golden/pubmed.csv --k $k --check --no-copy-probe >> $out 2>> ${out%.jsonl}.err || echo "{\"failed\": \"pubmed.csv $k\"}" >> $out
+  timeout -k 10 300 python bench.py --graph tests/golden/pubmed.csv --k $k --steps 1000 --warmup 20 --check --no-copy-probe >> $out 2>> ${out%.jsonl}.err || echo "{\"failed\": \"pubmed.csv $k\"}" >> $out
 done
 for cfg in "pubmed 32" "pubmed 128" "flickr 32" "flickr 128" "yelp 32" "yelp 128" "reddit 32" "reddit 128" "amazon 32" "amazon 128"; do
   set -- $cfg
