@@ -401,6 +401,21 @@ def test_bench_json_contract():
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] >= 1
     assert abs(j["value"] - 2 * j["config"]["nnz"] * j["config"]["k"] / (j["ms_per_step"] * 1e-3) / 1e9) < 0.01 * j["value"]
     assert j["hipsparse"]["value"] > 0
+    # the memory side is read from the card's counters inside the same run (N=1): source named, bytes split, both levels of B reuse
+    r = j["roofline"]
+    assert r["traffic_source"].startswith("in-run") and r["traffic"] == r["traffic_read_bytes"] + r["traffic_write_bytes"] > 0, r
+    assert 0 < r["l2_hit_rate"] <= 1 and r["l1_l2_bytes_measured"] > 0 and 0.8 < r["u_l1_measured"] < 2 and r["waves_per_launch"] > 0, r
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "3", "--workload", "flickr", "--no-cpu-baseline",
+                          "--no-vendor", "--no-copy-probe"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stdout + out.stderr
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])["roofline"]
+    # a graph that leaves the L2s: traffic above the algorithmic bytes, u at the L2 level defined and above the L1-level one
+    assert r["traffic"] > r["algorithmic_bytes_per_launch"] and r["u_l2_measured"] > r["u_l1_measured"] > 0.8, r
+    off = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "1", "--workload", "pubmed", "--k", "32", "--no-cpu-baseline",
+                          "--no-vendor", "--no-copy-probe", "--no-live-counters"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert off.returncode == 0, off.stdout + off.stderr
+    r = json.loads([ln for ln in off.stdout.splitlines() if ln.startswith("{")][0])["roofline"]
+    assert "u_l1_measured" not in r and (r["traffic_source"] is None or r["traffic_source"].startswith("profiles/")), r
 
 
 @pytest.mark.parametrize("dense_block", [False, True])
