@@ -95,7 +95,9 @@ def test_counters_match_known_byte_counts_and_bound_the_spmm_launch():
     o = _child()
     assert o["gpus"] >= 1
     assert abs(o["copy_read_ratio"] - 1) < 0.01 and abs(o["copy_write_ratio"] - 1) < 0.01, o
-    assert "accepted" not in o["both_in_one_pass"] and "accepted" not in o["bad_name"] and "NO_SUCH_COUNTER" in o["bad_name"], o
+    assert "accepted" not in o["bad_name"] and "NO_SUCH_COUNTER" in o["bad_name"], o
+    # FETCH_SIZE (3 slots) + WRITE_SIZE (2) do not fit the TCC block's 4: refused on ROCm 7.2; a stack that can schedule them may accept
+    assert o["both_in_one_pass"] == "accepted" or "flex_counters_begin" in o["both_in_one_pass"], o
     c_bytes, a_bytes, b_bytes = 4.0 * o["m"] * o["k"], 8.0 * o["nnz"] + 4.0 * (o["m"] + 1), 4.0 * o["n"] * o["k"]
     assert 0.98 * c_bytes <= o["write"] <= 1.10 * c_bytes, o          # split-row partials add a little
     assert 0.9 * (a_bytes + b_bytes) <= o["read"] <= a_bytes + 4.0 * o["nnz"] * o["k"], o
