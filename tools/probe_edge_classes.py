@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/probe_edge_classes.py [workload k] -- what the launch's bytes are made of: the stand-in generator's three classes of edges
 (inside a community / within the ring of +-8 communities / uniformly random) switched off one at a time, same n, nnz and degree law,
-flat kernel, community schedule; launch time and the in-run counters per point."""
+flat kernel (BLOCKS=1: the row-block route), community schedule; launch time and the in-run counters per point."""
 import json
 import os
 import sys
@@ -28,7 +28,8 @@ for label, p_in, p_near in points:
     B = torch.rand((a.n, k), device="cuda") * 2 - 1
     C = torch.empty((a.m, k), device="cuda")
     s = torch.cuda.current_stream().cuda_stream
-    p = flex_amd.Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER, tuning={"blocks": 2})
+    route = int(os.environ.get("BLOCKS", "2"))  # 2: flat kernel (default here), 1: the row-block route, 0: the planner's rule
+    p = flex_amd.Plan(a, k, order=flex_amd.FLEX_ORDER_CLUSTER, tuning={"blocks": route})
     n = 10 if a.nnz > 1e8 else 30
     us = timeit(p, B, C, n)
 
@@ -38,7 +39,7 @@ for label, p_in, p_near in points:
     t = counters.traffic(steps, sync=sync, launches=n)
     l2 = counters.count(steps, counters.L2_PASS, sync=sync)
     b_alg = 4.0 * (a.m + 1) + 8.0 * a.nnz + 8.0 * a.n * k
-    print(json.dumps({"workload": name, "k": k, "edges": label, "p_in": round(p_in, 3), "p_near": round(p_near, 3), "random": round(1 - p_in - p_near, 3),
+    print(json.dumps({"workload": name, "k": k, "route": {0: "rule", 1: "row blocks", 2: "flat"}[route], "blocks": p.info().get("n_blocks", 0), "edges": label, "p_in": round(p_in, 3), "p_near": round(p_near, 3), "random": round(1 - p_in - p_near, 3),
                       "nnz": a.nnz, "us": round(us, 1), "traffic_GB": round(t["traffic_bytes"] / 1e9, 2), "over_b_alg": round(t["traffic_bytes"] / b_alg, 2),
                       "traffic_TBps": round(t["traffic_bytes"] / us / 1e6, 2),
                       "l2_hit": round(l2["TCC_HIT_sum"] / max(1.0, l2["TCC_HIT_sum"] + l2["TCC_MISS_sum"]), 4),
