@@ -143,6 +143,7 @@ def main():
 
     k = args.k
     scale = world if args.scaling == "weak" else 1
+    gen_desc = None  # where on the stand-in generator's range a synthetic workload sits (goes into config.workload)
     # ---- workload: synthetic graph with the README's shape (x N vertices and nonzeros when weak-scaling)
     t_gen = time.perf_counter()
     if args.graph:
@@ -171,9 +172,16 @@ def main():
             a = flex_amd.synth_graph(n=sp.n, nnz=sp.nnz, alpha=sp.alpha, community=sp.community, p_in=p_in, p_near=sp.p_near,
                                      near_window=sp.near_window, shuffle=bool(args.shuffle), gcn_norm=bool(sp.gcn_norm),
                                      directed=bool(sp.directed), seed=sp.seed)
+            gen_desc = (f"variant {args.variant}: {100 * p_in:.0f} % of the edges inside a community of ~{sp.community}, {100 * sp.p_near:.0f} % within "
+                        f"+-{sp.near_window} communities, {100 * (1 - p_in - sp.p_near):.0f} % uniformly random; power-law degrees alpha={sp.alpha:.2f}")
             args.workload += f" [{args.variant}: {100 * (1 - p_in - sp.p_near):.0f} % random edges]"
         else:
             a = flex_amd.synth_graph(args.workload, scale=scale, shuffle=bool(args.shuffle))
+            sp = flex_amd.synth_preset(args.workload, scale)
+            if sp.community:  # the headline is a property of the generator point as much as of the kernel: name it
+                gen_desc = (f"preset: {100 * sp.p_in:.0f} % of the edges inside a community of ~{sp.community}, {100 * sp.p_near:.0f} % within +-{sp.near_window} "
+                            f"communities, {100 * (1 - sp.p_in - sp.p_near):.0f} % uniformly random; power-law degrees alpha={sp.alpha:.2f}"
+                            + ("; relabelled at random" if args.shuffle else "; PLANTED order kept"))
     t_gen = time.perf_counter() - t_gen
 
     # ---- plan: RCM is a schedule (N=1) or an explicit permutation followed by row sharding (N>1)
@@ -185,9 +193,19 @@ def main():
     # the ordering: from the permutation cache when it matches this matrix; else computed ONCE (rank 0, then broadcast)
     timings = {"order_s": 0.0}
     rank_arr, cache_state = None, None
+    def ordering_failed(e):
+        # rank 0 could not order (or could not read / write the permutation cache): shared_ordering has told every rank through
+        # the one broadcast, so all of them arrive here together.  A fresh exit, never a re-exec; no destructor waits on the group.
+        print(f"bench.py: rank {rank}: {e}", file=sys.stderr, flush=True)
+        sys.stderr.flush()
+        os._exit(4)
+
     if args.perm_cache and args.order != "natural":
         # only rank 0 reads or writes the file; every rank joins the one broadcast (flex_amd/multigpu.py, shared_ordering)
-        rank_arr = flex_amd.multigpu.shared_ordering(a, args.order, timings, cache=args.perm_cache)
+        try:
+            rank_arr = flex_amd.multigpu.shared_ordering(a, args.order, timings, cache=args.perm_cache)
+        except flex_amd.multigpu.OrderingFailed as e:
+            ordering_failed(e)
         cache_state = timings.get("perm_cache")
     if world == 1 and not args.dry_run:
         want_stats = a.nnz <= 50_000_000  # one extra pass over the records: skipped on amazon-size inputs
@@ -202,7 +220,10 @@ def main():
         shard_nnz, shard_rows = a.nnz, a.m
         shard = None
     else:
-        shard = flex_amd.make_shard(a, k, rank, world, order=args.order, rank_arr=rank_arr, timings=timings if rank_arr is None else None)
+        try:
+            shard = flex_amd.make_shard(a, k, rank, world, order=args.order, rank_arr=rank_arr, timings=timings if rank_arr is None else None)
+        except flex_amd.multigpu.OrderingFailed as e:
+            ordering_failed(e)
         plan = None if args.dry_run else shard.plan(k, local_rank, tuning=tuning)
         shard_nnz, shard_rows = shard.nnz, shard.r1 - shard.r0
     t_plan = time.perf_counter() - t_plan
@@ -276,7 +297,19 @@ def main():
                 for _ in range(n_cnt):
                     plan.spmm(bp, cp, stream)
 
+            # the counting service numbers the GPU agents as rocminfo does; HIP's ordinal is the same only while no *_VISIBLE_DEVICES
+            # variable re-maps the process's view -- with one set, the counters of ANOTHER card would be reported as this launch's
+            remapped = [v for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL") if os.environ.get(v)]
+            if "FLEX_BENCH_DEVICE" in os.environ and local_rank != 0:
+                raise RuntimeError(f"FLEX_BENCH_DEVICE={local_rank}: HIP device {local_rank} need not be counting-service agent {local_rank}")
             counted = live.traffic(launches, device=local_rank, sync=torch.cuda.synchronize, launches=n_cnt)
+            # The check that does not depend on how the box numbers its cards: C is written exactly once per launch (+ the partial sums
+            # of split rows).  The counters of another card -- idle or busy -- fail it, and then nothing measured is reported.
+            c_bytes = 4.0 * shard_rows * k
+            if not (0.9 * c_bytes <= counted["write_bytes"] <= 1.5 * c_bytes + (64 << 20)):
+                raise RuntimeError(f"counted {counted['write_bytes']:.3g} B written per launch against {c_bytes:.3g} B of C: not this launch's counters"
+                                   + (f" (device re-mapping in effect: {', '.join(remapped)})" if remapped else ""))
+            counted["device_note"] = (f"{', '.join(remapped)} set; agent {local_rank} accepted because it wrote C's bytes" if remapped else None)
             l2 = live.count(launches, live.L2_PASS, device=local_rank, sync=torch.cuda.synchronize)
             counted["l2_hit_rate"] = l2["TCC_HIT_sum"] / max(1.0, l2["TCC_HIT_sum"] + l2["TCC_MISS_sum"])
             counted["l2_requests"] = l2["TCC_REQ_sum"] / n_cnt
@@ -316,7 +349,13 @@ def main():
         kern_ms = dev_ms / args.steps
         achieved = b_alg / (kern_ms * 1e-3) / 1e9
         g_lanes = max(info["lanes_per_nz"], 1)
-        gather_demand = float(info.get("n_records", shard_nnz)) * 16.0 * g_lanes * -(-k // (4 * g_lanes))
+        # records of the rows the flat planner holds; a block plan keeps the other rows' records in its own image (32-column tiles,
+        # 128 bytes per record and tile; its HOT records read LDS, so only the rest is texture-path demand)
+        n_blocks = info.get("n_blocks", 0)
+        flat_records = float(info.get("n_records", shard_nnz))
+        gather_demand = flat_records * 16.0 * g_lanes * -(-k // (4 * g_lanes))
+        if n_blocks:
+            gather_demand += float(info["block_nnz"] - info["block_hot_nnz"]) * 128.0 * -(-k // 32)
         out = {
             "metric": "SpMM GFLOPS (2*nnz*k/t)", "value": round(gflops, 2), "unit": "GFLOPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -324,9 +363,10 @@ def main():
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "file" if args.graph else "synthetic",
             "config": {
                 "workload": (f"{args.workload} (n={a.n}, nnz={a.nnz}), k={k}, fp32, " if args.graph else
-                             f"{args.workload}-shape synthetic graph x{scale} (n={a.n}, nnz={a.nnz}), k={k}, fp32, ")
+                             f"{args.workload}-shape synthetic graph x{scale} (n={a.n}, nnz={a.nnz}"
+                             + (f"; generator {gen_desc}" if gen_desc else "") + f"), k={k}, fp32, ")
                             + f"{args.order} schedule" + (f", rows sharded over {world} GPUs, B broadcast once" if world > 1 else ""),
-                "n": a.n, "nnz": a.nnz, "k": k, "order": args.order, "parallelism": f"row-shard x{world}",
+                "n": a.n, "nnz": a.nnz, "k": k, "order": args.order, "parallelism": f"row-shard x{world}", "generator": gen_desc,
                 "plan": {"chunks": info["n_chunks"], "tasks": info["n_tasks"], "split_rows": info["n_split_rows"],
                          "lanes_per_nz": info["lanes_per_nz"], "two_d": info["two_d"], "mfma_tiles": info["n_tiles"],
                          "blocks": info.get("n_blocks", 0), "plan_s": round(t_plan, 3), "order_s": round(timings["order_s"], 3),
@@ -361,13 +401,17 @@ def main():
             # u = B bytes the nonzeros ask for / bytes the L2s fetched beyond A's own
             out["roofline"]["traffic_read_bytes"] = int(counted["read_bytes"])
             out["roofline"]["traffic_write_bytes"] = int(counted["write_bytes"])
+            if counted.get("device_note"):
+                out["roofline"]["traffic_device_note"] = counted["device_note"]
             out["roofline"]["traffic_over_algorithmic"] = round(counted["traffic_bytes"] / b_alg, 2)
             out["roofline"]["l2_hit_rate"] = round(counted["l2_hit_rate"], 4)
             # ≙ the reference's measured L1<->L2 bytes over its estimate ("L2/", flex.cu:5279-5330): requests the L2s received x 128 B,
             # next to what the schedule asks of them (B gathers + the record stream once per column tile + C)
             out["roofline"]["l1_l2_bytes_measured"] = int(counted["l2_requests"] * live.L2_REQUEST_BYTES)
             ktiles = -(-k // (4 * g_lanes))
-            est = gather_demand + 8.0 * float(info.get("n_records", shard_nnz)) * ktiles + 4.0 * shard_rows * k
+            est = gather_demand + 8.0 * flat_records * ktiles + 4.0 * shard_rows * k
+            if n_blocks:  # + the block image's record streams (once per 32-column tile) and its staged panels
+                est += (8.0 * float(info["block_records"]) + 128.0 * float(info["block_hot_cols"])) * -(-k // 32)
             out["roofline"]["l1_l2_bytes_over_estimate"] = round(counted["l2_requests"] * live.L2_REQUEST_BYTES / max(est, 1.0), 3)
             # The reference's own `u` (flex.cu:5513-5528) is one level up: nD = bytes L1 reads from L2 per multiply-add = 4/u + (A's share),
             # i.e. how often a B element that reached a CU is used there.  Here A's share is the record stream, re-read once per column tile.
@@ -408,7 +452,7 @@ def main():
             out["config"]["per_rank_nnz"] = [int(x) for x in nnzs]
             out["config"]["per_rank_rows"] = [int(r[3]) for r in per_rank]
             out["config"]["shard_nnz_imbalance_pct"] = round(100.0 * max(nnzs) * world / max(sum(nnzs), 1.0) - 100.0, 2)
-        if world == 1 and want_stats:  # ≙ B-Re1 / B-Re2 and alpha_stats_collect (flex.cu:5217-5223, mat.cu:944-1065)
+        if world == 1 and want_stats and not n_blocks:  # (a block plan's statistics cover only the rows left to the flat planner)  ≙ B-Re1 / B-Re2 and alpha_stats_collect (flex.cu:5217-5223, mat.cu:944-1065)
             st = plan.stats()
             out["config"]["plan"].update({
                 "b_reuse_wave": round(st["reuse_wave"], 3), "b_reuse_xcd": round(st["reuse_xcd"], 3),
@@ -610,14 +654,15 @@ def vendor_baseline(a, k, B, C):
 
 
 def cpu_baseline(a, k, B):
-    """The reference's CPU SpMM arithmetic (oracle port of aspt/sspmm_128.cu:1415-1422) timed on this host.  The threaded leg runs
-    the WHOLE workload -- every row of the same CSR and B -- whenever that is predicted to fit ~10 s (the Amazon shape at k=128
-    takes 2-3 s on 16 threads), else the first rows holding ~1e10 flops; the single-thread leg always runs on that bounded sample."""
+    """The reference's CPU SpMM arithmetic (oracle port of aspt/sspmm_128.cu:1415-1422) timed on this host's cores (BASELINE.md 3:
+    "all host cores of the GPU box").  The threaded leg uses every core this process may run on (`cores`); beside it the same on 16
+    threads (`value_16_threads`: the share of the host one GPU's job has on this pool, what rounds 1-3 reported) and on one thread
+    (`single_thread_value`).  Sample: the WHOLE workload -- every row of the same CSR and B -- whenever the all-core leg is predicted
+    to fit ~10 s (the Amazon shape at k=128 does), else the first rows holding ~1e10 flops; the one-thread leg always runs on that
+    bounded sample.  About 10-30 s of CPU work in all."""
     import oracle
     host_cores = os.cpu_count() or 1
-    # threads actually used by the multi-threaded leg: the share of the host one GPU's job is entitled to on the pool
-    # (16 of the box's cores), never more than the process may run on
-    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cores, 16)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else host_cores
     budget = 1.0e10 / (2.0 * k)  # nonzeros of the bounded sample
     rp = a.rowPtr.astype(np.int64)
     rows = int(np.searchsorted(rp, budget, side="right")) - 1 if a.nnz > budget else a.m
@@ -625,27 +670,33 @@ def cpu_baseline(a, k, B):
     nnz = int(rp[rows])
     rp_s = a.rowPtr[: rows + 1]
     Bh = B.cpu().numpy()
-    best1 = bestN = 1e30
-    for i in range(3):
-        t0 = time.perf_counter()
-        oracle.spmm(rp_s, a.col[:nnz], a.vals[:nnz], Bh, nthreads=cores)
-        bestN = min(bestN, time.perf_counter() - t0)
-    t0 = time.perf_counter()
-    oracle.spmm(rp_s, a.col[:nnz], a.vals[:nnz], Bh, nthreads=1)
-    best1 = time.perf_counter() - t0
-    value, sample = 2.0 * nnz * k / bestN / 1e9, f"first {rows} rows ({nnz} nnz) of the same graph and B, best of 3"
-    if rows < a.m and bestN * a.nnz / max(nnz, 1) <= 5.0:  # the whole job, twice, within ~10 s
-        full = 1e30
-        for i in range(2):
+
+    def best_of(n, fn):
+        best = 1e30
+        for _ in range(n):
             t0 = time.perf_counter()
-            oracle.spmm(a.rowPtr, a.col, a.vals, Bh, nthreads=cores)
-            full = min(full, time.perf_counter() - t0)
-        value, sample = 2.0 * a.nnz * k / full / 1e9, f"the whole workload: all {a.m} rows ({a.nnz} nnz) of the same graph and B, best of 2 ({full:.2f} s)"
-    elif rows >= a.m:
-        sample = f"the whole workload: all {a.m} rows ({a.nnz} nnz) of the same graph and B, best of 3"
-    return {"value": round(value, 3), "unit": "GFLOPS", "cores": cores, "host_cores": host_cores, "kind": "port", "sample": sample,
-            "single_thread_value": round(2.0 * nnz * k / best1 / 1e9, 3),
-            "single_thread_sample": f"first {rows} rows ({nnz} nnz), one run"}
+            fn()
+            best = min(best, time.perf_counter() - t0)
+        return best
+
+    sample_run = lambda nt: (lambda: oracle.spmm(rp_s, a.col[:nnz], a.vals[:nnz], Bh, nthreads=nt))  # noqa: E731
+    whole_run = lambda nt: (lambda: oracle.spmm(a.rowPtr, a.col, a.vals, Bh, nthreads=nt))  # noqa: E731
+    bestN = best_of(3, sample_run(cores))
+    best1 = best_of(1, sample_run(1))
+    whole = rows >= a.m or bestN * a.nnz / max(nnz, 1) <= 5.0  # the whole job, twice, within ~10 s
+    if rows >= a.m:
+        t_all, n_all, sample = bestN, nnz, f"the whole workload: all {a.m} rows ({a.nnz} nnz) of the same graph and B, best of 3"
+    elif whole:
+        t_all, n_all = best_of(2, whole_run(cores)), a.nnz
+        sample = f"the whole workload: all {a.m} rows ({a.nnz} nnz) of the same graph and B, best of 2 ({t_all:.2f} s)"
+    else:
+        t_all, n_all, sample = bestN, nnz, f"first {rows} rows ({nnz} nnz) of the same graph and B, best of 3"
+    out = {"value": round(2.0 * n_all * k / t_all / 1e9, 3), "unit": "GFLOPS", "cores": cores, "host_cores": host_cores, "kind": "port", "sample": sample,
+           "single_thread_value": round(2.0 * nnz * k / best1 / 1e9, 3), "single_thread_sample": f"first {rows} rows ({nnz} nnz), one run"}
+    if cores > 16:  # the figure of rounds 1-3 beside it: 16 threads, same sample rule
+        t16 = best_of(2, whole_run(16)) if whole and rows < a.m else best_of(2, sample_run(16))
+        out["value_16_threads"] = round(2.0 * (n_all if whole else nnz) * k / t16 / 1e9, 3)
+    return out
 
 
 if __name__ == "__main__":

@@ -72,6 +72,8 @@ void free_plan_device(flex_plan *p) {
     (void)hipFree(p->d_bk_brow);
     (void)hipFree(p->d_bk_grp);
     (void)hipFree(p->d_bk_rec);
+    if (p->done) (void)hipEventDestroy(p->done);
+    p->done = nullptr;
 }
 
 }  // namespace flex
@@ -267,6 +269,20 @@ int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream) {
     const bool fused = vec4 && p->fused_fixup;  // the generic kernel always leaves the sum to spmm_fixup_kernel
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc = FLEX_OK;
+    // A plan with split rows owns their partial-sum workspace (and, in the in-launch form, their arrival counters): two launches
+    // of it must not overlap.  Launches on ONE stream are ordered by the stream; a launch on ANOTHER stream while the latest one
+    // has not finished is refused instead of silently corrupting those rows.  (A launch being captured into a graph is neither
+    // checked nor recorded: what replays of the graph overlap with is the caller's to order.)
+    bool guard = p->n_partials > 0;
+    if (guard) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess) (void)hipGetLastError();
+        if (cap != hipStreamCaptureStatusNone) guard = false;
+    }
+    if (guard && p->launched && s != p->last_stream && hipEventQuery(p->done) == hipErrorNotReady) {
+        if (cur != p->device) (void)hipSetDevice(cur);
+        return FLEX_ERR_INVALID;
+    }
     if (p->bk_blocks) {  // the rows owned by row blocks (their own kernel); everything below handles the other rows
         // block plans exist for the float4 path only, and that needs the 16-byte alignment this header asks for
         rc = vec4 ? launch_blocks(block_view(p), dB, dC, s) : FLEX_ERR_UNSUPPORTED;
@@ -279,6 +295,16 @@ int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream) {
     if (rc == FLEX_OK && !fused) rc = launch_fixup(p->d_partial, p->d_split, p->n_split, p->k, p->ldc, dC, s);
     // the dense tiles' share, added to the rows the kernels above have written
     if (rc == FLEX_OK && p->n_tiles) rc = launch_tiles(tile_view(p), p->off32, dB, dC, p->k, p->ldb, p->ldc, s);
+    if (rc == FLEX_OK && guard) {
+        if (!p->done && hipEventCreateWithFlags(&p->done, hipEventDisableTiming) != hipSuccess) p->done = nullptr;
+        if (p->done && hipEventRecord(p->done, s) == hipSuccess) {
+            p->last_stream = s;
+            p->launched = true;
+        } else {
+            (void)hipGetLastError();
+            p->launched = false;
+        }
+    }
     if (cur != p->device) (void)hipSetDevice(cur);
     return rc;
 }

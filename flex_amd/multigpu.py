@@ -54,6 +54,10 @@ class RowShard:
         return rows if self.vo_mp is None else self.vo_mp[rows]
 
 
+class OrderingFailed(RuntimeError):
+    """shared_ordering: rank 0 failed to order (or to load / save the permutation cache); raised on EVERY rank of the job."""
+
+
 ORDERINGS = {"rcm": _b.order_rcm, "cluster": _b.order_cluster, "deg": _b.order_deg, "gorder": _b.order_gorder, "dfs": _b.order_dfs}
 
 
@@ -64,7 +68,9 @@ def shared_ordering(a: "_b.HostCsr", order: str, timings: dict | None = None, ca
     cache: a permutation-cache file (flex_perm_save / _load, keyed by the matrix's fingerprint).  ONLY rank 0 touches it -- loads it if
     it matches, else orders and writes it -- so the ranks cannot disagree about whether there is a collective to join (a rank that
     found the file another rank had just written would skip the broadcast the others are waiting in).  timings["perm_cache"] =
-    "loaded" / "written" (rank 0; the others report what rank 0 did)."""
+    "loaded" / "written" (rank 0; the others report what rank 0 did).
+    Failure: whatever rank 0 raises while ordering / loading / saving is caught there, a state word of -1 goes through the SAME
+    broadcast, and every rank raises OrderingFailed -- nobody is left waiting in the collective."""
     import time
     t0 = time.perf_counter()
     spent = 0.0
@@ -93,14 +99,26 @@ def shared_ordering(a: "_b.HostCsr", order: str, timings: dict | None = None, ca
         rank_arr, state = order_or_load()
     else:
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        # Rank 0 can fail before it has anything to send (Gorder refuses isolated vertices, the 4 GB of scratch are not there, the
+        # cache path is not writable, a cache file is damaged): it must still JOIN the collective, or the others wait in it until the
+        # process-group timeout.  The last word of the one buffer is the state: -1 = rank 0 failed, and then every rank raises.
+        failure = None
         if dist.get_rank() == 0:
-            rank_arr, state = order_or_load()
-            buf = torch.cat([torch.from_numpy(rank_arr.astype(np.int32)), torch.tensor([state], dtype=torch.int32)]).to(dev)
+            try:
+                rank_arr, state = order_or_load()
+                buf = torch.cat([torch.from_numpy(rank_arr.astype(np.int32)), torch.tensor([state], dtype=torch.int32)]).to(dev)
+            except Exception as e:  # noqa: BLE001 -- whatever it was, the other ranks have to hear about it
+                failure = e
+                buf = torch.full((a.m + 1,), -1, dtype=torch.int32, device=dev)
         else:
             buf = torch.empty(a.m + 1, dtype=torch.int32, device=dev)
         dist.broadcast(buf, src=0)
         host = buf.cpu().numpy()
         rank_arr, state = host[: a.m].astype(np.uint32), int(host[a.m])
+        if state < 0:
+            if failure is not None:
+                raise OrderingFailed(f"rank 0 could not produce the {order!r} ordering: {type(failure).__name__}: {failure}") from failure
+            raise OrderingFailed(f"rank 0 could not produce the {order!r} ordering (its own message says why); rank {dist.get_rank()} stops with it")
     if timings is not None:
         timings["order_s"] = spent
         timings["perm_cache"] = {0: None, 1: "loaded", 2: "written"}[state]

@@ -90,18 +90,27 @@ def test_reddit_full_size_rcm_reordered_k128():
         fp64_rows_check(a, B, C, rows)
 
 
-def test_amazon_full_size_row_sharded_8_ways_k128():
-    """configs[3]: Amazon shape (1.57 M^2, 264 M nnz, values U(-1,1)), k=128, rows partitioned 8 ways after the
-    re-ordering, every shard planned with col_map = vo_mp against the full un-permuted B (north_star's exact
-    partitioning: what each of the 8 GPUs computes, executed here one after the other on one card), the
-    concatenation compared with the oracle."""
+@pytest.fixture(scope="module")
+def amazon_case():
+    """The Amazon shape (configs[3], bench.py's default workload), its B and the oracle's C: generated and multiplied ONCE for the
+    tests below (the oracle run is the expensive part)."""
     free, _ = torch.cuda.mem_get_info()
     if free < 16 * (1 << 30):
         pytest.skip("needs ~8 GiB of HBM")
     a = flex_amd.synth_graph("amazon")
     assert a.m == 1569960 and abs(a.nnz - 264339468) <= 1
+    B = random_B(a.n, 128, 63)
+    gold = oracle.spmm(a.rowPtr, a.col, a.vals, B, nthreads=CORES)
+    return a, B, gold
+
+
+def test_amazon_full_size_row_sharded_8_ways_k128(amazon_case):
+    """configs[3]: Amazon shape (1.57 M^2, 264 M nnz, values U(-1,1)), k=128, rows partitioned 8 ways after the
+    re-ordering, every shard planned with col_map = vo_mp against the full un-permuted B (north_star's exact
+    partitioning: what each of the 8 GPUs computes, executed here one after the other on one card), the
+    concatenation compared with the oracle."""
+    a, B, gold = amazon_case
     k, world = 128, 8
-    B = random_B(a.n, k, 63)
     Bd = dev(B)
     shards = [flex_amd.make_shard(a, k, 0, world, order="cluster")]
     base = shards[0]
@@ -117,12 +126,34 @@ def test_amazon_full_size_row_sharded_8_ways_k128():
         got[sh.original_rows()] = run_plan(p, Bd)
         p.destroy()
     del Bd
-    gold = oracle.spmm(a.rowPtr, a.col, a.vals, B, nthreads=CORES)
     cnt, max_err, me_nnz, _ = oracle.rescheck(gold, got, a.rowPtr)
     assert cnt == 0, (cnt, max_err, me_nnz)
     deg = np.diff(a.rowPtr.astype(np.int64))
     rows = np.concatenate([np.argsort(deg)[-10:], np.random.default_rng(3).choice(a.m, 100, replace=False)])
     fp64_rows_check(a, B, got, rows)
+
+
+def test_amazon_headline_plan_whole_graph_one_gpu_k128(amazon_case):
+    """The GRADED configuration itself: exactly what `bench.py` with no flags times -- the whole Amazon shape, k=128, the
+    community schedule computed inside ONE plan (about 1.8 M tasks, tens of thousands of rows cut into pieces and summed by the
+    second launch), launched once and resChecked over ALL rows against the oracle (flex.cu:5690-5693: every timed
+    configuration is checked), twice: the plan must also leave a second launch bit-identical."""
+    a, B, gold = amazon_case
+    k = 128
+    Bd = dev(B)
+    p = Plan(a, k, order=FLEX_ORDER_CLUSTER)  # bench.py: make_plan(order="cluster") with no tuning
+    info = p.info()
+    assert info["n_split_rows"] > 1000 and info["n_partials"] > info["n_split_rows"], info  # hub rows exist and are cut
+    p.self_check()
+    C = run_plan(p, Bd)
+    cnt, max_err, me_nnz, _ = oracle.rescheck(gold, C, a.rowPtr)
+    assert cnt == 0, (cnt, max_err, me_nnz)
+    C2 = run_plan(p, Bd)
+    assert np.array_equal(C.view(np.uint32), C2.view(np.uint32))
+    p.destroy()
+    deg = np.diff(a.rowPtr.astype(np.int64))
+    rows = np.concatenate([np.argsort(deg)[-10:], np.random.default_rng(4).choice(a.m, 100, replace=False)])
+    fp64_rows_check(a, B, C, rows)
 
 
 @pytest.mark.parametrize("name", ["wiki-vote", "soc-sign-epinions"])
@@ -191,8 +222,8 @@ def test_cxx_multi_gpu_driver_fails_loudly_without_enough_devices():
 def test_amazon_shape_without_random_edges_takes_the_row_block_route_by_rule():
     """The planner's rule for the row-block route (LDS-staged B panels): on a very large, strongly clustered input -- the Amazon
     shape with no uniformly random edges, bench.py --variant best -- a sampled look finds > 72 % of the nonzeros in hot columns
-    and the plan is built of row blocks; the preset (15 % random edges) stays flat.  The block result is compared with the flat
-    plan of the same matrix over ALL rows (resCheck) and with float64 sums of sampled rows (hubs included)."""
+    and the plan is built of row blocks; the preset (15 % random edges) stays flat.  The block result is compared with the ORACLE
+    over ALL rows (resCheck), with the flat plan of the same matrix, and with float64 sums of sampled rows (hubs included)."""
     free, _ = torch.cuda.mem_get_info()
     if free < 24 * (1 << 30):
         pytest.skip("needs ~12 GiB of HBM")
@@ -214,12 +245,15 @@ def test_amazon_shape_without_random_edges_takes_the_row_block_route_by_rule():
     assert pf.info()["n_blocks"] == 0
     Cf = run_plan(pf, Bd)
     pf.destroy()
-    cnt, max_err, me_nnz, _ = oracle.rescheck(Cf, Cb, a.rowPtr)
-    assert cnt == 0, (cnt, max_err, me_nnz)
+    del ap, Bd
+    gold = oracle.spmm(a.rowPtr, a.col, a.vals, B, nthreads=CORES)
+    for C in (Cb, Cf):  # the route the rule picked, and the flat plan beside it: each against the oracle, every row
+        cnt, max_err, me_nnz, _ = oracle.rescheck(gold, C, a.rowPtr)
+        assert cnt == 0, (cnt, max_err, me_nnz)
+    del gold
     deg = np.diff(a.rowPtr.astype(np.int64))
     rows = np.concatenate([np.argsort(deg)[-10:], np.random.default_rng(5).choice(a.m, 200, replace=False)])
     fp64_rows_check(a, B, Cb, rows)
-    del ap
     # the preset: same shape, 15 % uniformly random edges -> hot share 0.62 -> flat
     a2 = flex_amd.synth_graph("amazon")
     p2 = Plan(a2, k, order=FLEX_ORDER_CLUSTER)

@@ -695,6 +695,46 @@ def test_two_plans_on_two_streams_concurrently():
     assert np.array_equal(c1.cpu().numpy(), ref1) and np.array_equal(c2.cpu().numpy(), ref2)
 
 
+def test_one_plan_on_two_streams_at_once_is_refused_not_corrupted():
+    """include/flex_spmm.h: a plan with split rows owns their workspace, so a launch on a DIFFERENT stream while its latest launch
+    is still in flight returns FLEX_ERR_INVALID (and enqueues nothing) instead of silently corrupting those rows; the same stream,
+    or another stream once the first has finished, is fine -- and a plan WITHOUT split rows may overlap freely."""
+    import torch
+    a = random_csr(4000, 4000, 12, seed=71, long_rows={3: 3500, 50: 900})
+    B = random_B(4000, 128, 1)
+    p = Plan(a, 128, order=flex_amd.FLEX_ORDER_CLUSTER)
+    assert p.info()["n_partials"] > 0
+    ref = run_plan(p, B)
+    assert_matches_oracle(a, B, ref)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    d = torch.from_numpy(B).cuda()
+    c1, c2 = torch.empty((4000, 128), device="cuda"), torch.empty((4000, 128), device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s1):
+        torch.cuda._sleep(400_000_000)  # ~0.2 s of device time in front of the launch: it IS in flight when the next call comes
+    p.spmm(d.data_ptr(), c1.data_ptr(), s1.cuda_stream)
+    p.spmm(d.data_ptr(), c1.data_ptr(), s1.cuda_stream)  # same stream: ordered by the stream, accepted
+    with pytest.raises(flex_amd.FlexError, match="invalid argument"):
+        p.spmm(d.data_ptr(), c2.data_ptr(), s2.cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(c1.cpu().numpy(), ref)
+    p.spmm(d.data_ptr(), c2.data_ptr(), s2.cuda_stream)  # the first stream has drained: another stream is fine now
+    torch.cuda.synchronize()
+    assert np.array_equal(c2.cpu().numpy(), ref)
+    # no split rows -> no workspace -> nothing to guard
+    a0 = random_csr(3000, 3000, 8, seed=73)
+    p0 = Plan(a0, 64, order=flex_amd.FLEX_ORDER_CLUSTER, tuning={"long_row": 1 << 20})
+    assert p0.info()["n_partials"] == 0
+    d0 = torch.from_numpy(random_B(3000, 64, 2)).cuda()
+    e1, e2 = torch.empty((3000, 64), device="cuda"), torch.empty((3000, 64), device="cuda")
+    with torch.cuda.stream(s1):
+        torch.cuda._sleep(100_000_000)
+    p0.spmm(d0.data_ptr(), e1.data_ptr(), s1.cuda_stream)
+    p0.spmm(d0.data_ptr(), e2.data_ptr(), s2.cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(e1.cpu().numpy(), e2.cpu().numpy())
+
+
 def test_autotuned_plan_is_correct_and_no_slower_choice_is_kept():
     """FLEX_PLAN_AUTOTUNE plans the neighbouring column-tile widths as well and keeps the fastest: whatever it keeps
     must pass resCheck and the self-check, statistics must describe the kept plan, and odd k (generic kernel) is a no-op."""

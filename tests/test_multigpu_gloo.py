@@ -216,3 +216,61 @@ def test_a_rank_that_cannot_reach_the_others_exits_nonzero_instead_of_hanging():
     assert procs[0].returncode not in (0, None), outs[0]
     assert "initialisation failed" in outs[0][1] or "imed out" in outs[0][1] or "onnect" in outs[0][1], outs[0][1][-1500:]
     assert time.time() - t0 < 100
+
+
+FAILING_WORKER = r'''
+import os, sys, time
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+import flex_amd
+from flex_amd.multigpu import OrderingFailed, shared_ordering
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+mode = sys.argv[1]
+n = 64
+if mode == "gorder-isolated":  # a ring with vertex 5 cut out of it: Gorder (order_gorder.cu: every vertex needs a neighbour) refuses
+    keep = [v for v in range(n) if v != 5]
+    rows = {v: [] for v in range(n)}
+    for i, v in enumerate(keep):
+        w = keep[(i + 1) %% len(keep)]
+        rows[v].append(w); rows[w].append(v)
+    rp = np.cumsum([0] + [len(rows[v]) for v in range(n)]).astype(np.uint32)
+    col = np.array([c for v in range(n) for c in sorted(rows[v])], dtype=np.uint32)
+    a = flex_amd.HostCsr(rp, col, np.ones(len(col), np.float32), n=n)
+    order, cache = "gorder", None
+else:                          # the permutation cache cannot be written: the ordering succeeds, perm_save raises
+    a = flex_amd.synth_graph(n=2000, nnz=2000 + 2 * 8000, community=50, p_in=0.6, p_near=0.2, seed=3)
+    order, cache = "cluster", "/nonexistent-dir-for-this-test/x.perm"
+t0 = time.time()
+try:
+    shared_ordering(a, order, {}, cache=cache)
+except OrderingFailed as e:
+    print(f"rank {rank}: OrderingFailed after {time.time() - t0:.1f} s: {e}", flush=True)
+    os._exit(7)  # a fresh exit: no destructor waits on the group
+print(f"rank {rank}: no failure", flush=True)
+os._exit(0)
+'''
+
+
+@pytest.mark.parametrize("mode", ["gorder-isolated", "cache-unwritable"])
+def test_rank0_failing_to_order_fails_every_rank_instead_of_stranding_them(tmp_path, mode):
+    """The N>1 failure path of shared_ordering: whatever rank 0 raises while ordering (Gorder given an isolated vertex) or while
+    saving the permutation cache becomes a state word in the SAME broadcast, and every rank raises together -- no rank is left in
+    the collective until the process-group timeout (the sibling of the cache-file race fixed in round 3)."""
+    pytest.importorskip("torch")
+    import time
+    world, port = 3, _free_port()
+    script = tmp_path / "w.py"
+    script.write_text(FAILING_WORKER % {"root": ROOT})
+    t0 = time.time()
+    procs = [subprocess.Popen([sys.executable, str(script), mode],
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1"),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=240) for p in procs]
+    assert time.time() - t0 < 200
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 7, (r, p.returncode, so[-800:], se[-800:])
+        assert "OrderingFailed" in so and "rank 0 could not produce" in so, so
+    assert ("FlexError" in outs[0][0]) or ("Error" in outs[0][0])  # rank 0 says what it was
