@@ -43,7 +43,13 @@ def parse():
                          "(none: every edge inside a community or its ring) or `worst` (40 %%); same n, nnz and degree law.  The headline is the preset; "
                          "the other two bracket what the numbers owe to the generator (DESIGN.md 3.4).  --workload rmat20: no communities at all")
     ap.add_argument("--k", type=int, default=128)
-    ap.add_argument("--order", default="cluster", choices=["cluster", "rcm", "natural"])
+    ap.add_argument("--order", default="cluster", choices=["cluster", "rcm", "natural"],
+                    help="cluster / natural: the row schedule of the plan.  rcm (BASELINE configs[2], 'RCM-reordered rows'): the matrix is RCM-reordered "
+                         "on the host as the reference's DataLoaderRcm does (DataLoader.cu:723-787: permuted CSR + vo_mp) and that loader is the plan's "
+                         "INPUT; see --schedule for how its rows are then scheduled")
+    ap.add_argument("--schedule", default="auto", choices=["auto", "as-given", "cluster"],
+                    help="N=1, --order rcm only: `cluster` (= auto) lays the engine's community schedule over the reordered loader "
+                         "(flex_plan_create_mapped(A', vo_mp, FLEX_ORDER_CLUSTER)); `as-given` walks the loader's rows in RCM order (rounds 1-3)")
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"])
     ap.add_argument("--shuffle", type=int, default=1, help="0: keep the generator's planted order (locality upper bound)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -189,6 +195,7 @@ def main():
     order = {"cluster": flex_amd.FLEX_ORDER_CLUSTER, "rcm": flex_amd.FLEX_ORDER_RCM,
              "natural": flex_amd.FLEX_ORDER_NATURAL}[args.order]
     want_stats = False
+    schedule_name = f"{args.order} schedule"
     tuning = {kv.split("=")[0].strip(): int(kv.split("=")[1]) for kv in args.tuning.split(",") if kv.strip()} or None
     # the ordering: from the permutation cache when it matches this matrix; else computed ONCE (rank 0, then broadcast)
     timings = {"order_s": 0.0}
@@ -210,12 +217,23 @@ def main():
     if world == 1 and not args.dry_run:
         want_stats = a.nnz <= 50_000_000  # one extra pass over the records: skipped on amazon-size inputs
         flags = (flex_amd.FLEX_PLAN_STATS if want_stats else 0) | (flex_amd.FLEX_PLAN_AUTOTUNE if args.autotune else 0)
-        if rank_arr is None:
+        if args.order == "rcm":
+            # configs[2]: the RCM-reordered LOADER is the input (the reference's flow: permuted CSR + vo_mp, B and C stay in the
+            # original order); the schedule on top of it is the engine's -- communities, unless --schedule as-given
+            t_o = time.perf_counter()
+            if rank_arr is None:
+                rank_arr = flex_amd.order_rcm(a)
+                timings["order_s"] = time.perf_counter() - t_o
+            vo, ap = flex_amd.perm_csr(a, rank_arr)
+            over = flex_amd.FLEX_PLAN_XCD_INTERLEAVE if args.schedule == "as-given" else flex_amd.FLEX_ORDER_CLUSTER
+            plan = flex_amd.Plan(ap, k, device=local_rank, vo_mp=vo, tuning=tuning, order=flags | over)
+            schedule_name = "RCM-reordered loader (vo_mp), rows walked " + ("as given" if args.schedule == "as-given" else "in the community schedule found on top of it")
+            del ap
+        elif rank_arr is None:
             plan = flex_amd.Plan(a, k, device=local_rank, order=order | flags, tuning=tuning)
         else:  # the reference's flow: a reordered loader + vo_mp, planned in the order given
             vo, ap = flex_amd.perm_csr(a, rank_arr)
-            plan = flex_amd.Plan(ap, k, device=local_rank, vo_mp=vo, tuning=tuning,
-                                 order=flags | (flex_amd.FLEX_PLAN_XCD_INTERLEAVE if args.order == "rcm" else 0))
+            plan = flex_amd.Plan(ap, k, device=local_rank, vo_mp=vo, tuning=tuning, order=flags)
             del ap
         shard_nnz, shard_rows = a.nnz, a.m
         shard = None
@@ -365,8 +383,8 @@ def main():
                 "workload": (f"{args.workload} (n={a.n}, nnz={a.nnz}), k={k}, fp32, " if args.graph else
                              f"{args.workload}-shape synthetic graph x{scale} (n={a.n}, nnz={a.nnz}"
                              + (f"; generator {gen_desc}" if gen_desc else "") + f"), k={k}, fp32, ")
-                            + f"{args.order} schedule" + (f", rows sharded over {world} GPUs, B broadcast once" if world > 1 else ""),
-                "n": a.n, "nnz": a.nnz, "k": k, "order": args.order, "parallelism": f"row-shard x{world}", "generator": gen_desc,
+                            + schedule_name + (f", rows sharded over {world} GPUs, B broadcast once" if world > 1 else ""),
+                "n": a.n, "nnz": a.nnz, "k": k, "order": args.order, "schedule": schedule_name, "parallelism": f"row-shard x{world}", "generator": gen_desc,
                 "plan": {"chunks": info["n_chunks"], "tasks": info["n_tasks"], "split_rows": info["n_split_rows"],
                          "lanes_per_nz": info["lanes_per_nz"], "two_d": info["two_d"], "mfma_tiles": info["n_tiles"],
                          "blocks": info.get("n_blocks", 0), "plan_s": round(t_plan, 3), "order_s": round(timings["order_s"], 3),

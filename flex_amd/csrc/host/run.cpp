@@ -235,6 +235,9 @@ void run(DataLoader &input_vo) {
     {
         DataLoaderRcm rcm(input_vo);
         bench_one(rcm, FLEX_ORDER_NATURAL, "natural", input_vo, h_res.get(), perfRes, rows, stats_log);
+        // BASELINE configs[2] as worded -- an RCM-reordered loader is the INPUT (DataLoader.cu:723-787); how its rows are scheduled
+        // on eight private L2s is the engine's: the community schedule on top of the loader's order
+        bench_one(rcm, FLEX_ORDER_CLUSTER, "cluster", input_vo, h_res.get(), perfRes, rows, stats_log);
     }
     {
         DataLoaderRabbit rbt(input_vo);

@@ -706,12 +706,17 @@ class PlanBuilder {
         std::vector<uint32_t> zeros(std::max<size_t>(1, split.size() * ktiles), 0u);
         if ((rc = upload(&p->d_split_cnt, zeros, &p->device_bytes))) return rc;
         const size_t pbytes = std::max<size_t>(1, static_cast<size_t>(n_partials) * k) * sizeof(float);
-        // Split rows are summed by spmm_fixup_kernel after the main launch: stream order is all that needs, and it measured
+        // Large launches: split rows are summed by spmm_fixup_kernel after the main launch: stream order is all that needs, and it measured
         // FASTER than the in-launch form on the large shapes (MI355X, profiles/r03_fixup_in_launch_vs_two_launch.txt: reddit k=128
         // 638 vs 642 us, amazon 8.22 vs 8.27 ms; flickr 38.5 vs 36.7 us and reddit k=32 151 vs 150 the other way: one kernel
         // boundary).  tuning.split_rows = 1 asks for the in-launch form (relaxed agent atomics + sc1 hand-off: measured on
         // gfx950, not an architectural guarantee; spmm_kernels.hip).
-        p->fused_fixup = tn.split_rows == 1;
+        // Round 4: which form, by SIZE.  A launch of a few tens of microseconds pays the kernel boundary of the second launch in
+        // full (flickr shape k=128: 36.5-36.7 us in-launch against 38.5-40.0 with spmm_fixup_kernel; reddit k=32, 150 us: level),
+        // a launch of milliseconds gains from having no arrival atomics and reducer tails inside its 2 M waves -- so the in-launch
+        // form is the rule up to 4e8 multiply-adds per launch and the two-launch form above.  tuning.split_rows = 1 / 2 forces.
+        const double madds = static_cast<double>(slice_nnz()) * k;
+        p->fused_fixup = tn.split_rows == 1 || (tn.split_rows != 2 && madds <= 4e8);
         p->tuning.split_rows = p->fused_fixup ? 1 : 2;
         FLEX_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p->d_partial), pbytes));
         p->device_bytes += static_cast<int64_t>(pbytes);

@@ -80,13 +80,21 @@ def test_reddit_full_size_rcm_reordered_k128():
     C2 = run_plan(p2, Bd)
     assert oracle.rescheck(gold, C2, a.rowPtr)[0] == 0
     p2.destroy()
+    # (2b) configs[2] as worded, and what `bench.py --workload reddit --order rcm` times: the RCM-reordered loader is the INPUT,
+    # the community schedule is laid over it by the plan (flex_plan_create_mapped(A', vo_mp, FLEX_ORDER_CLUSTER))
+    p2b = Plan(ap, k, vo_mp=vo, order=FLEX_ORDER_CLUSTER)
+    assert p2b.info()["order"] == FLEX_ORDER_CLUSTER
+    p2b.self_check()
+    C2b = run_plan(p2b, Bd)
+    assert oracle.rescheck(gold, C2b, a.rowPtr)[0] == 0
+    p2b.destroy()
     # (3) what bench.py --workload reddit times
     C3 = run_plan(Plan(a, k, order=FLEX_ORDER_CLUSTER), Bd)
     assert oracle.rescheck(gold, C3, a.rowPtr)[0] == 0
     # fp64 cross-check that shares nothing with the oracle: sampled rows, including the heaviest
     deg = np.diff(a.rowPtr.astype(np.int64))
     rows = np.concatenate([np.argsort(deg)[-20:], np.random.default_rng(2).choice(a.m, 200, replace=False)])
-    for C in (C1, C2, C3):
+    for C in (C1, C2, C2b, C3):
         fp64_rows_check(a, B, C, rows)
 
 

@@ -181,9 +181,11 @@ def test_knobs_travel_in_the_descriptor_not_in_the_environment(sim, monkeypatch)
     monkeypatch.setenv("FLEX_FUSED_FIXUP", "1")
     p = flex_amd.Plan(a, 128)
     t = p.tuning()
-    assert p.info()["two_d"] == 0 and t["lanes_per_nz"] == 16 and t["split_rows"] == 2  # rules, whatever the environment says
-    # the default is the two-launch sum of split rows; the in-launch form has to be asked for
-    assert flex_amd.Plan(a, 128, tuning={"split_rows": 1}).tuning()["split_rows"] == 1
+    assert p.info()["two_d"] == 0 and t["lanes_per_nz"] == 16 and t["split_rows"] == 1  # rules, whatever the environment says
+    # the form of the split-row sum goes by size (in-launch up to 4e8 multiply-adds per launch, two launches above); either can be forced
+    assert flex_amd.Plan(a, 128, tuning={"split_rows": 2}).tuning()["split_rows"] == 2
+    big = flex_amd.synth_graph(n=60000, nnz=60000 + 2 * 2000000, community=500, p_in=0.55, p_near=0.3, seed=6)
+    assert flex_amd.Plan(big, 128).tuning()["split_rows"] == 2 and flex_amd.Plan(big, 128, tuning={"split_rows": 1}).tuning()["split_rows"] == 1
     got, errs = {}, []
     def make(name, knobs, rounds=6):
         try:
