@@ -48,51 +48,51 @@ struct TileView {
     uint32_t n_row_tiles;
 };
 
-// ---- the row-block path (block_kernels.hip, block_plan.cpp): LDS-level reuse of B.
-// A BLOCK is R = rounds x 120 row slots of schedule-consecutive rows, owned by ONE workgroup of 16 waves (15 consumer waves x 8
-// slots of 8 lanes + 1 loader wave).  Columns that at least `thr` nonzeros of the block use are HOT: their B rows (one 32-column
-// tile = 128 bytes each) are staged panel by panel into LDS by the loader wave (LDS-DMA, double-buffered) and every use reads
-// them with ds_read_b128; the block's other nonzeros (COLD) gather from global memory as the flat kernel does.  A slot walks ONE
-// row (or one part of a long row) through all phases with its sum in registers, so C is written once and nothing is combined
-// across workgroups.
+// ---- the hot-block path (block_kernels.hip, block_plan.cpp): LDS-level reuse of B for the nonzeros that have it.
+// Round 4 design.  The matrix is SPLIT: a nonzero whose column is used by at least `thr` nonzeros of its BLOCK (R = rounds x 60
+// schedule-consecutive rows) is HOT and lives in the block image below; every other nonzero -- and every row too long for a
+// slot -- stays in the flat plan, whose kernel is the one that moves L2 misses at the fabric's rate.  flex_spmm runs the flat
+// kernel first (it writes every row of C), then spmm_hot_kernel ADDS the hot part: one workgroup of 16 waves per (block, 64-column
+// tile): 15 CONSUMER waves of 4 slots x 16 lanes + 1 LOADER wave.  A slot holds ONE C row per round in registers (the lane owns 4
+// of the tile's 64 columns); the hot B rows (256 bytes per row and tile) are staged panel by panel into LDS by the loader wave
+// (LDS-DMA, double-buffered) and every use is a ds_read_b128 that is bank-conflict free by construction (a 16-lane slot reads one
+// whole 256-byte row = all 64 banks).  Records never touch LDS: a RUN (the <= 16 steps of one (wave, panel, round)) is one coalesced
+// 512-byte load into a register pair a whole panel ahead, and step j's record reaches the 16 lanes of its slot by a DPP row
+// broadcast (row_newbcast:j) -- the LDS pipe carries nothing but B.
 #ifndef FLEX_BK_WAVES
 #define FLEX_BK_WAVES 15
 #endif
 constexpr int kBkWaves = FLEX_BK_WAVES;                   // consumer waves per workgroup
-constexpr int kBkSlots = 8;                               // slots per wave (8 lanes x float4 = one 32-column tile of one row)
-constexpr int kBkRowsPerRound = kBkWaves * kBkSlots;      // 120 row slots per round
+constexpr int kBkSlots = 4;                               // slots per wave (16 lanes x float4 = one 64-column tile of one row)
+constexpr int kBkTileCols = 64;                           // columns of C per pass
+constexpr int kBkRowsPerRound = kBkWaves * kBkSlots;      // 60 row slots per round
 constexpr int kBkMaxRounds = 8;
-#ifndef FLEX_BK_PANEL_MAX  // experiments build variants (make -C flex_amd/csrc block_variants); the product has one value
-#define FLEX_BK_PANEL_MAX 480
-#endif
-#ifndef FLEX_BK_WIN_STEPS
-#define FLEX_BK_WIN_STEPS 32
+constexpr uint32_t kBkRunMax = 16;                        // steps of one run = lanes of a slot: what one DPP row holds
+#ifndef FLEX_BK_PANEL_MAX  // experiment builds may vary it; the product has one value
+#define FLEX_BK_PANEL_MAX 304
 #endif
 constexpr uint32_t kBkPanelMax = FLEX_BK_PANEL_MAX;       // B rows per LDS panel
-constexpr uint32_t kBkRowBytes = 128;                     // one B row of one column tile
-constexpr uint32_t kBkZeroRow = kBkPanelMax * kBkRowBytes; // byte offset, inside a panel buffer, of TWO rows of zeros (an even and an odd panel row: padding records point at them)
-constexpr uint32_t kBkBufBytes = kBkZeroRow + 2 * kBkRowBytes;
-constexpr uint32_t kBkWinSteps = FLEX_BK_WIN_STEPS;       // record window per consumer wave: 32 steps x 8 slots x 8 bytes = 2 KiB
-constexpr uint32_t kBkLdsWin = 2 * kBkBufBytes;
-constexpr uint32_t kBkLdsHcol = kBkLdsWin + kBkWaves * kBkWinSteps * kBkSlots * 8;
-constexpr uint32_t kBkLdsBytes = kBkLdsHcol + 2 * kBkPanelMax * 4;  // 157 696 of the CU's 163 840
-static_assert(kBkLdsBytes <= 163840 && kBkPanelMax % 8 == 0 && kBkWinSteps % 8 == 0, "the block kernel's LDS image must fit one CU");
-constexpr uint32_t kBkEmptyRow = 0x1FFFFFFFu;             // brow entry of a slot that holds no row
-constexpr uint32_t kBkMaxCounts = 256;                    // (1 + panels) x rounds step counts per wave, two per lane-held word
+constexpr uint32_t kBkRowBytes = 256;                     // one B row of one column tile
+constexpr uint32_t kBkZeroRow = kBkPanelMax * kBkRowBytes; // byte offset, inside a panel buffer, of a row of zeros (padding records point at it)
+constexpr uint32_t kBkBufBytes = kBkZeroRow + kBkRowBytes;
+constexpr uint32_t kBkLdsHcol = 2 * kBkBufBytes;
+constexpr uint32_t kBkLdsBytes = kBkLdsHcol + 2 * kBkPanelMax * 4;  // 158 592 of the CU's 163 840
+static_assert(kBkLdsBytes <= 163840 && kBkPanelMax % 4 == 0 && kBkPanelMax <= 512, "the hot kernel's LDS image must fit one CU");
+constexpr uint32_t kBkEmptyRow = 0xFFFFFFFFu;             // brow entry of a slot that holds no row
+constexpr uint32_t kBkMaxCounts = 256;                    // panels x rounds step counts per wave, two per lane-held word
 
 struct BlockView {
-    const uint4 *hdr;        // [n_blocks] {panels | hub flag << 31, first entry in hcol, first word in cnt, words of cnt per wave}
+    const uint4 *hdr;        // [n_blocks] {panels, first entry in hcol, first word in cnt, words of cnt per wave}
     const uint2 *wstart;     // [n_blocks][15] {first step of the wave's record stream, its steps}
-    const uint32_t *cnt;     // per (block, wave): 16-bit step counts, phase-major [1 + panels][rounds], two per word
+    const uint32_t *cnt;     // per (block, wave): 16-bit step counts of its runs, panel-major [panels][rounds], two per word
     const uint32_t *hcol;    // per (block, panel): panel_rows byte offsets of the B rows staged (padded with a valid one)
-    const uint32_t *brow;    // [n_blocks][rounds][15][8] C row of the slot (bits 0-28) | log2(slots of its row) << 29; kBkEmptyRow = none
-    const uint32_t *bgrp;    // [n_blocks][rounds][15] 0, or for a group that holds one of the g >= 2 parts of a HUB row (a row spread over g whole
-                             // groups on g waves): part | g << 8 | (first scratch slot of the row) << 16; hdr.x bit 31 says the block has such rows
-    const uint2 *rec;        // [steps][8] {cold phase: byte offset of the B row; panel phases: byte offset inside the panel buffer, value bits}
+    const uint32_t *brow;    // [n_blocks][rounds][15][4] C row of the slot; kBkEmptyRow = none
+    const uint2 *rec;        // [steps][4] {byte offset inside the panel buffer, value bits}
+    uint64_t n_rec;          // records in `rec` (loads past a wave's stream are clamped to the last one)
     uint32_t n_blocks, rounds, panel_rows;
     int32_t k, ldb, ldc;
     uint32_t xcd_remap;
-    uint32_t ablate;         // timing-only (tools/probe_blocks.py; results are WRONG): 1 no panel DMA, 2 no panel-phase work, 4 no cold-phase work
+    uint32_t ablate;         // timing-only (tools/probe_blocks.py; results are WRONG): 1 no panel DMA, 2 no panel work
     uint64_t *trace;         // -DFLEX_TRACE builds only (tools/trace_blocks.py): 8 cycle counters per (tile, block, wave); else nullptr
 };
 
