@@ -367,13 +367,11 @@ def main():
         kern_ms = dev_ms / args.steps
         achieved = b_alg / (kern_ms * 1e-3) / 1e9
         g_lanes = max(info["lanes_per_nz"], 1)
-        # records of the rows the flat planner holds; a block plan keeps the other rows' records in its own image (32-column tiles,
-        # 128 bytes per record and tile; its HOT records read LDS, so only the rest is texture-path demand)
+        # records of the flat plan; a plan with hot blocks keeps the nonzeros that have reuse on chip in its block image (64-column
+        # tiles: 256 bytes of LDS per record and tile, a staged B row per hot column and tile)
         n_blocks = info.get("n_blocks", 0)
         flat_records = float(info.get("n_records", shard_nnz))
-        gather_demand = flat_records * 16.0 * g_lanes * -(-k // (4 * g_lanes))
-        if n_blocks:
-            gather_demand += float(info["block_nnz"] - info["block_hot_nnz"]) * 128.0 * -(-k // 32)
+        gather_demand = flat_records * 16.0 * g_lanes * -(-k // (4 * g_lanes))  # (the hot blocks' nonzeros read LDS, not the texture path)
         out = {
             "metric": "SpMM GFLOPS (2*nnz*k/t)", "value": round(gflops, 2), "unit": "GFLOPS",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -387,7 +385,8 @@ def main():
                 "n": a.n, "nnz": a.nnz, "k": k, "order": args.order, "schedule": schedule_name, "parallelism": f"row-shard x{world}", "generator": gen_desc,
                 "plan": {"chunks": info["n_chunks"], "tasks": info["n_tasks"], "split_rows": info["n_split_rows"],
                          "lanes_per_nz": info["lanes_per_nz"], "two_d": info["two_d"], "mfma_tiles": info["n_tiles"],
-                         "blocks": info.get("n_blocks", 0), "plan_s": round(t_plan, 3), "order_s": round(timings["order_s"], 3),
+                         "blocks": info.get("n_blocks", 0), "block_hot_nnz": info.get("block_hot_nnz", 0), "block_hot_cols": info.get("block_hot_cols", 0),
+                         "block_records": info.get("block_records", 0), "block_panels": info.get("block_panels", 0), "plan_s": round(t_plan, 3), "order_s": round(timings["order_s"], 3),
                          "gen_s": round(t_gen, 3), "host_threads": host_threads, "perm_cache": cache_state},
                 "b_bcast_ms": round(bcast_ms, 3),
                 # ≙ the README's "tPre/tElap" column (README.md:34-42): preprocessing (ordering + planning + upload) over
@@ -402,7 +401,7 @@ def main():
                          "traffic_source": (f"in-run: rocprofiler-sdk device counting service, {counted['launches_per_pass']} launches per pass after the "
                                             "timed region, 2*FETCH_SIZE + WRITE_SIZE (KiB)" if counted else
                                             "profiles/pmc_traffic.json (rocprofv3 --pmc passes of tools/pmc.sh)" if _pmc_traffic(args, world) is not None else None),
-                         "kernel": "spmm_block_kernel + spmm_flat_kernel" if info.get("n_blocks", 0) else "spmm_flat_kernel", "kernel_ms": round(kern_ms, 6),
+                         "kernel": "spmm_flat_kernel + spmm_hot_kernel" if info.get("n_blocks", 0) else "spmm_flat_kernel", "kernel_ms": round(kern_ms, 6),
                          "algorithmic_bytes_per_launch": int(b_alg),
                          # what the flat kernel asks of the texture path: every record pulls one B-row segment of 16*G
                          # bytes, once per column tile, L2 hit or not.  NOT a roof: with every gather an L2 hit this kernel moves those
@@ -428,8 +427,8 @@ def main():
             out["roofline"]["l1_l2_bytes_measured"] = int(counted["l2_requests"] * live.L2_REQUEST_BYTES)
             ktiles = -(-k // (4 * g_lanes))
             est = gather_demand + 8.0 * flat_records * ktiles + 4.0 * shard_rows * k
-            if n_blocks:  # + the block image's record streams (once per 32-column tile) and its staged panels
-                est += (8.0 * float(info["block_records"]) + 128.0 * float(info["block_hot_cols"])) * -(-k // 32)
+            if n_blocks:  # + the block image's record streams (once per 64-column tile), its staged panels and its second pass over C
+                est += (8.0 * float(info["block_records"]) + 256.0 * float(info["block_hot_cols"])) * -(-k // 64) + 8.0 * float(info["block_rows"]) * k
             out["roofline"]["l1_l2_bytes_over_estimate"] = round(counted["l2_requests"] * live.L2_REQUEST_BYTES / max(est, 1.0), 3)
             # The reference's own `u` (flex.cu:5513-5528) is one level up: nD = bytes L1 reads from L2 per multiply-add = 4/u + (A's share),
             # i.e. how often a B element that reached a CU is used there.  Here A's share is the record stream, re-read once per column tile.
@@ -470,7 +469,7 @@ def main():
             out["config"]["per_rank_nnz"] = [int(x) for x in nnzs]
             out["config"]["per_rank_rows"] = [int(r[3]) for r in per_rank]
             out["config"]["shard_nnz_imbalance_pct"] = round(100.0 * max(nnzs) * world / max(sum(nnzs), 1.0) - 100.0, 2)
-        if world == 1 and want_stats and not n_blocks:  # (a block plan's statistics cover only the rows left to the flat planner)  ≙ B-Re1 / B-Re2 and alpha_stats_collect (flex.cu:5217-5223, mat.cu:944-1065)
+        if world == 1 and want_stats and not n_blocks:  # (with hot blocks the statistics would cover the flat plan's nonzeros only)  ≙ B-Re1 / B-Re2 and alpha_stats_collect (flex.cu:5217-5223, mat.cu:944-1065)
             st = plan.stats()
             out["config"]["plan"].update({
                 "b_reuse_wave": round(st["reuse_wave"], 3), "b_reuse_xcd": round(st["reuse_xcd"], 3),

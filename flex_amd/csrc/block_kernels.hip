@@ -45,7 +45,7 @@ __device__ __forceinline__ void fma4(v4f &acc, float v, const v4f &b) {
 // lane J of every 16-lane row, to all lanes of that row (DPP row_newbcast: gfx90a and later)
 template <int J>
 __device__ __forceinline__ uint32_t row_bcast(uint32_t v) {
-    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x150 + J, 0xf, 0xf, false));
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x150 + J, 0xf, 0xf, true));
 }
 
 // LDS is handed from the loader to the consumers (and back) by plain workgroup barriers.  Consumers keep their record
@@ -147,10 +147,11 @@ __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_hot_kernel(BlockView
 #endif
     const uint32_t slot = static_cast<uint32_t>(lane) >> 4;
     const uint2 ws = v.wstart[static_cast<uint64_t>(blk) * kBkWaves + w];
-    const uint2 *__restrict__ rec = v.rec + static_cast<uint64_t>(ws.x) * kBkSlots;
-    // the last record this wave may touch: loads that run past the end of its stream read the NEXT wave's records (harmless: such
-    // steps are never executed), loads past the end of the whole array are clamped
-    const uint32_t last_rec = static_cast<uint32_t>(min(v.n_rec - 1 - static_cast<uint64_t>(ws.x) * kBkSlots, static_cast<uint64_t>(0xFFFFFFFFu)));
+    // Loads that run past the end of this wave's stream read the NEXT wave's records (harmless: such steps are never executed);
+    // loads past the end of the whole array are clamped to its last record (v.n_rec >= 1).
+    const uint64_t first_rec = min(static_cast<uint64_t>(ws.x) * kBkSlots, v.n_rec - 1);
+    const uint2 *__restrict__ rec = v.rec + first_rec;
+    const uint32_t last_rec = static_cast<uint32_t>(min(v.n_rec - 1 - first_rec, static_cast<uint64_t>(0xFFFFFFFFu)));
     // step counts of the runs: two 16-bit counts per word, the words held one per lane
     const uint32_t cw = hdr.w;
     const uint32_t *__restrict__ cnt = v.cnt + hdr.z + static_cast<uint64_t>(w) * cw;

@@ -70,7 +70,6 @@ void free_plan_device(flex_plan *p) {
     (void)hipFree(p->d_bk_cnt);
     (void)hipFree(p->d_bk_hcol);
     (void)hipFree(p->d_bk_brow);
-    (void)hipFree(p->d_bk_grp);
     (void)hipFree(p->d_bk_rec);
     if (p->done) (void)hipEventDestroy(p->done);
     p->done = nullptr;
@@ -283,18 +282,16 @@ int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream) {
         if (cur != p->device) (void)hipSetDevice(cur);
         return FLEX_ERR_INVALID;
     }
-    if (p->bk_blocks) {  // the rows owned by row blocks (their own kernel); everything below handles the other rows
-        // block plans exist for the float4 path only, and that needs the 16-byte alignment this header asks for
-        rc = vec4 ? launch_blocks(block_view(p), dB, dC, s) : FLEX_ERR_UNSUPPORTED;
-        if (rc) {
-            if (cur != p->device) (void)hipSetDevice(cur);
-            return rc;
-        }
+    if (p->bk_blocks && !vec4) {  // block plans exist for the float4 path only, and that needs the 16-byte alignment this header asks for
+        if (cur != p->device) (void)hipSetDevice(cur);
+        return FLEX_ERR_UNSUPPORTED;
     }
     rc = launch_spmm(plan_view(p, fused, p->trace), p->lanes_per_nz, p->off32, vec4, dB, dC, s, p->unroll);
     if (rc == FLEX_OK && !fused) rc = launch_fixup(p->d_partial, p->d_split, p->n_split, p->k, p->ldc, dC, s);
     // the dense tiles' share, added to the rows the kernels above have written
     if (rc == FLEX_OK && p->n_tiles) rc = launch_tiles(tile_view(p), p->off32, dB, dC, p->k, p->ldb, p->ldc, s);
+    // the hot blocks' share (the nonzeros with reuse on chip: B rows staged in LDS), added to the rows the flat kernel has written
+    if (rc == FLEX_OK && p->bk_blocks) rc = launch_blocks(block_view(p), dB, dC, s);
     if (rc == FLEX_OK && guard) {
         if (!p->done && hipEventCreateWithFlags(&p->done, hipEventDisableTiming) != hipSuccess) p->done = nullptr;
         if (p->done && hipEventRecord(p->done, s) == hipSuccess) {

@@ -5,6 +5,7 @@
 //   dense_tiles.cpp   the block-density detector and the dense-tile store of the MFMA route
 //   plan_check.cpp    what is read back from a finished plan: self-check, statistics, measured imbalance
 #pragma once
+#include <algorithm>
 #include <cstdlib>
 #include <memory>
 #include <new>
@@ -44,10 +45,11 @@ struct flex_plan {
     int64_t tile_hist[3] = {0, 0, 0}, tile_cells = 0;  // detector report
     bool tile_hist_valid = false;
     uint32_t panel_rows = 0;
-    // row blocks (block_kernels.hip): the rows they own are not in the task / chunk arrays above
+    // hot blocks (block_kernels.hip): the nonzeros they hold are not in the record stream above; their rows are (the flat kernel
+    // writes every row, the hot kernel adds to the rows of its blocks)
     uint4 *d_bk_hdr = nullptr;
     uint2 *d_bk_wstart = nullptr, *d_bk_rec = nullptr;
-    uint32_t *d_bk_cnt = nullptr, *d_bk_hcol = nullptr, *d_bk_brow = nullptr, *d_bk_grp = nullptr;
+    uint32_t *d_bk_cnt = nullptr, *d_bk_hcol = nullptr, *d_bk_brow = nullptr;
     uint32_t bk_blocks = 0, bk_rounds = 0, bk_panel_rows = 0, bk_ablate = 0;
     int64_t bk_rows = 0, bk_nnz = 0, bk_hot_nnz = 0, bk_hot_cols = 0, bk_panels = 0, bk_records = 0;
     uint32_t n_tasks = 0, n_chunks = 0, n_slots = 0, n_split = 0, n_partials = 0;  // n_slots: chunk table incl. padding
@@ -107,8 +109,8 @@ inline PlanView plan_view(const flex_plan *p, bool fused, uint64_t *trace) {
                     p->xcd_remap ? 1u : 0u, p->lds_extra, p->rec_nt ? 1u : 0u, p->tile_group, trace};
 }
 inline BlockView block_view(const flex_plan *p) {
-    return BlockView{p->d_bk_hdr, p->d_bk_wstart, p->d_bk_cnt, p->d_bk_hcol, p->d_bk_brow, p->d_bk_grp, p->d_bk_rec, p->bk_blocks, p->bk_rounds, p->bk_panel_rows,
-                     p->k, p->ldb, p->ldc, 1u, p->bk_ablate, p->trace};
+    return BlockView{p->d_bk_hdr, p->d_bk_wstart, p->d_bk_cnt, p->d_bk_hcol, p->d_bk_brow, p->d_bk_rec, static_cast<uint64_t>(std::max<int64_t>(p->bk_records, 1)),
+                     p->bk_blocks, p->bk_rounds, p->bk_panel_rows, p->k, p->ldb, p->ldc, 1u, p->bk_ablate, p->trace};
 }
 inline TileView tile_view(const flex_plan *p) { return TileView{p->d_tile_a, p->d_tile_boff, p->d_tile_mask, p->d_rt_ptr, p->d_rt_rows, p->n_row_tiles}; }
 // float4 path: k and both strides multiples of 4, both base addresses 16-byte aligned
@@ -139,14 +141,14 @@ int detect_dense_tiles(const flex_csr *A, int32_t r0, int32_t m, const std::vect
                        const int32_t *col_map, const int32_t *dst_map, bool off32, uint32_t row_bytes32, uint32_t thr, int64_t stride,
                        std::vector<uint8_t> &in_tile, DenseTiles &out);
 
-// ---- row blocks (block_plan.cpp)
+// ---- hot blocks (block_plan.cpp)
 struct BlockKnobs {
-    uint32_t rounds = 4, panel_rows = kBkPanelMax, thr = 2, cap = 512, max_panels = 30, min_last_panel = 64;
+    uint32_t rounds = 8, panel_rows = kBkPanelMax, thr = 2, cap = 1024, max_panels = 31, min_last_panel = 32, run_max = kBkRunMax;
 };
 struct BlockImage {  // host copy of what BlockView points at
     std::vector<uint4> hdr;
     std::vector<uint2> wstart;
-    std::vector<uint32_t> cnt, hcol, brow, grp;
+    std::vector<uint32_t> cnt, hcol, brow;
     RecordVec rec;
     uint32_t n_blocks = 0, rounds = 0, panel_rows = 0;
     int64_t rows = 0, nnz = 0, hot_nnz = 0, hot_cols = 0, panels = 0;
@@ -154,9 +156,10 @@ struct BlockImage {  // host copy of what BlockView points at
 // What share of the nonzeros of rows sched[...] would be HOT (their column used by >= thr nonzeros of the same block of `rows`
 // schedule-consecutive rows), looked at in every `stride`-th block: the planner's cheap look before it commits to the block route.
 double estimate_hot_share(const flex_csr *A, const std::vector<uint32_t> &sched, uint32_t rows, uint32_t thr, int64_t stride, double *u = nullptr);
-// Rows sched[0..) of A (a row's C row: dst_map, or r - r0) into blocks; `rest` receives the schedule positions that stay flat.
+// Rows sched[0..) of A (a row's C row: dst_map, or r - r0) into blocks.  hot_mask[e - rowPtr[r0]] = 1 for every nonzero that went
+// into the block image; the caller plans the OTHER nonzeros with the flat planner.
 int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const std::vector<uint32_t> &colpos, const int32_t *col_map,
-                 const int32_t *dst_map, int32_t r0, uint32_t row_bytes32, const BlockKnobs &kn, BlockImage &img, std::vector<uint32_t> &rest);
+                 const int32_t *dst_map, int32_t r0, uint32_t row_bytes32, const BlockKnobs &kn, BlockImage &img, std::vector<uint8_t> &hot_mask);
 
 // ---- plan_check.cpp
 void collect_stats(flex_plan *p, const RecordVec &rec, const std::vector<uint4> &chunk, int64_t split_nnz);

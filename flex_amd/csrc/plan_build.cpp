@@ -46,9 +46,9 @@ constexpr uint32_t kMaxTasksPerWave = 63;  // the kernel hands descriptors out b
 class PlanBuilder {
    public:
     PlanBuilder(flex_plan *plan, const flex_csr *csr, int32_t row_begin, int32_t row_end, const int32_t *col_map_, const int32_t *dst_map_,
-                unsigned flags_, const flex_plan_tuning &tuning, std::vector<uint32_t> *sched_cache_, int force_G_)
+                unsigned flags_, const flex_plan_tuning &tuning, std::vector<uint32_t> *sched_cache_, int force_G_, bool want_blocks_ = false)
         : p(plan), A(csr), r0(row_begin), r1(row_end), m(row_end - row_begin), k(plan->k), col_map(col_map_), dst_map(dst_map_),
-          flags(flags_), order(flags_ & FLEX_ORDER_MASK), force_G(force_G_), tn(tuning), sched(sched_cache_ ? *sched_cache_ : sched_local),
+          flags(flags_), order(flags_ & FLEX_ORDER_MASK), force_G(force_G_), want_blocks(want_blocks_), tn(tuning), sched(sched_cache_ ? *sched_cache_ : sched_local),
           have_cache(sched_cache_ != nullptr), timing(plan_timing_enabled()), t_last(std::chrono::steady_clock::now()) {}
 
     // The first two stages alone, for the row-block route (build_plan below): the schedule and its inverse.
@@ -78,6 +78,10 @@ class PlanBuilder {
         }
         if ((rc = route_dense_tiles())) return rc;
         lap("dense-tile detector");
+        if (want_blocks && tiles.nnz == 0 && m > 0) {  // the two routes do not combine (yet): dense tiles first
+            if ((rc = route_hot_blocks())) return rc;
+            lap("hot blocks");
+        }
         read_knobs();
         if ((rc = cut_rows_into_pieces())) return rc;
         lap("pieces");
@@ -105,6 +109,7 @@ class PlanBuilder {
     const int32_t *const dst_map;  // C row written by row r (NULL = r - r0)
     const unsigned flags, order;
     const int force_G;
+    const bool want_blocks;  // split the matrix: nonzeros with reuse inside a block of rows go to the hot-block image (block_plan.cpp)
     const flex_plan_tuning &tn;  // the caller's knobs: 0 = the rule of the stage that reads it; p->tuning receives what was used
     std::vector<uint32_t> sched_local;
     std::vector<uint32_t> &sched;  // sched[i] = row of A processed i-th
@@ -244,24 +249,92 @@ class PlanBuilder {
         }
         if (tiles.nnz == 0) return FLEX_OK;
         // the vector kernel gets A minus the entries that moved into tiles (same rows, same ids)
+        keep_unmarked(in_tile, static_cast<size_t>(nnz_in - tiles.nnz));
+        return FLEX_OK;
+    }
+
+    // A := A minus the entries of rows [r0,r1) whose mask byte is set (index e - rowPtr[r0]); same rows, same ids, order kept.
+    void keep_unmarked(const std::vector<uint8_t> &mask, size_t n_keep) {
         f_rowptr.assign(static_cast<size_t>(A->m) + 1, 0u);
-        f_col.resize(static_cast<size_t>(nnz_in - tiles.nnz));
-        f_vals.resize(static_cast<size_t>(nnz_in - tiles.nnz));
         const uint32_t eb = A->rowPtr[r0];
-        uint32_t o = 0;
-        for (int32_t r = 0; r < A->m; ++r) {
-            f_rowptr[r] = o;
-            if (r < r0 || r >= r1) continue;
-            for (uint32_t e = A->rowPtr[r]; e < A->rowPtr[r + 1]; ++e)
-                if (!in_tile[e - eb]) {
-                    f_col[o] = A->col[e];
-                    f_vals[o] = A->vals[e];
-                    ++o;
-                }
-        }
-        f_rowptr[A->m] = o;
-        A_f = flex_csr{A->m, A->n, static_cast<int64_t>(o), f_rowptr.data(), f_col.data(), f_vals.data()};
+        // per-row counts, then the prefix, then a parallel copy (the Amazon shape filters 264 M entries)
+        parallel_chunks((static_cast<int64_t>(m) + 4095) / 4096, [&](int64_t b) {
+            for (int64_t r = r0 + b * 4096; r < std::min<int64_t>(r1, r0 + (b + 1) * 4096); ++r) {
+                uint32_t c = 0;
+                for (uint32_t e = A->rowPtr[r]; e < A->rowPtr[r + 1]; ++e) c += mask[e - eb] ? 0u : 1u;
+                f_rowptr[r + 1] = c;
+            }
+        });
+        for (int32_t r = 0; r < A->m; ++r) f_rowptr[r + 1] += f_rowptr[r];
+        (void)n_keep;
+        f_col.resize(f_rowptr[A->m]);
+        f_vals.resize(f_rowptr[A->m]);
+        const flex_csr *src = A;
+        parallel_chunks((static_cast<int64_t>(m) + 4095) / 4096, [&](int64_t b) {
+            for (int64_t r = r0 + b * 4096; r < std::min<int64_t>(r1, r0 + (b + 1) * 4096); ++r) {
+                uint32_t o = f_rowptr[r];
+                for (uint32_t e = src->rowPtr[r]; e < src->rowPtr[r + 1]; ++e)
+                    if (!mask[e - eb]) {
+                        f_col[o] = src->col[e];
+                        f_vals[o] = src->vals[e];
+                        ++o;
+                    }
+            }
+        });
+        A_f = flex_csr{A->m, A->n, static_cast<int64_t>(f_rowptr[A->m]), f_rowptr.data(), f_col.data(), f_vals.data()};
         A = &A_f;
+    }
+
+    // The hot-block route (a SPLIT of the matrix).  Nonzeros whose column is used at least `thr` times
+    // inside their block of schedule-consecutive rows have reuse on chip: they go to the block image (block_plan.cpp; one
+    // workgroup per block stages those B rows in LDS).  Every other nonzero is an L2 miss under any schedule, and moving L2
+    // misses at the fabric's rate is what the flat kernel does best: it gets A minus the hot entries (same rows, same ids, same
+    // schedule), runs first and writes every C row; the hot kernel adds its part afterwards (flex_spmm).
+    int route_hot_blocks() {
+        BlockKnobs kn;
+        const int32_t rd = tn.block_rounds;
+        if (rd == 2 || rd == 4 || rd == 8) kn.rounds = static_cast<uint32_t>(rd);
+        else if (rd != 0) return FLEX_ERR_INVALID;
+        else if (m < 8 * 256 * 480) kn.rounds = m < 8 * 256 * 240 ? 2 : 4;  // smaller blocks while there are fewer than ~8 per CU
+        if (tn.block_panel_rows) {
+            if (tn.block_panel_rows % 4 != 0 || tn.block_panel_rows > static_cast<int32_t>(kBkPanelMax)) return FLEX_ERR_INVALID;
+            kn.panel_rows = static_cast<uint32_t>(tn.block_panel_rows);
+        }
+        kn.thr = tn.block_thr ? static_cast<uint32_t>(tn.block_thr) : 2u;
+        // a row longer than this takes no slot (all of it stays flat, where long rows are cut into concurrent pieces): its hot
+        // nonzeros would be runs of one slot several times longer than its neighbours'
+        kn.cap = tn.block_cap ? static_cast<uint32_t>(std::min<int32_t>(tn.block_cap, 60000)) : static_cast<uint32_t>(std::clamp(6.0 * avg_deg, 64.0, 4096.0));
+        kn.min_last_panel = std::min<uint32_t>(32, kn.panel_rows / 4);
+        BlockImage img;
+        std::vector<uint8_t> hot_mask;
+        const uint32_t row_bytes32 = static_cast<uint32_t>(p->ldb) * 4u;
+        int rc;
+        if ((rc = build_blocks(A, sched, colpos, col_map, dst_map, r0, row_bytes32, kn, img, hot_mask))) return rc;
+        flex_plan_tuning &u = p->tuning;
+        u.blocks = 1;
+        u.block_rounds = static_cast<int32_t>(kn.rounds);
+        u.block_panel_rows = static_cast<int32_t>(kn.panel_rows);
+        u.block_thr = static_cast<int32_t>(kn.thr);
+        u.block_cap = static_cast<int32_t>(kn.cap);
+        if (img.hot_nnz == 0) return FLEX_OK;  // nothing has reuse: a flat plan
+        if ((rc = upload(&p->d_bk_hdr, img.hdr, &p->device_bytes))) return rc;
+        if ((rc = upload(&p->d_bk_wstart, img.wstart, &p->device_bytes))) return rc;
+        if ((rc = upload(&p->d_bk_cnt, img.cnt, &p->device_bytes))) return rc;
+        if ((rc = upload(&p->d_bk_hcol, img.hcol, &p->device_bytes))) return rc;
+        if ((rc = upload(&p->d_bk_brow, img.brow, &p->device_bytes))) return rc;
+        if ((rc = upload(&p->d_bk_rec, img.rec, &p->device_bytes))) return rc;
+        p->bk_blocks = img.n_blocks;
+        p->bk_rounds = img.rounds;
+        p->bk_panel_rows = img.panel_rows;
+        p->bk_rows = img.rows;
+        p->bk_nnz = img.nnz;
+        p->bk_hot_nnz = img.hot_nnz;
+        p->bk_hot_cols = img.hot_cols;
+        p->bk_panels = img.panels;
+        p->bk_records = static_cast<int64_t>(img.rec.size());
+        p->bk_ablate = static_cast<uint32_t>(tn.block_ablate);
+        img = BlockImage{};
+        keep_unmarked(hot_mask, 0);
         return FLEX_OK;
     }
 
@@ -726,123 +799,32 @@ class PlanBuilder {
 
 }  // namespace
 
-// The row-block route: rows go to blocks (block_plan.cpp: one workgroup each, hot B rows staged in LDS); what the
-// blocks do not take -- empty rows, rows longer than 8 x cap -- becomes a small CSR of its own, in schedule order, with a
-// row map, and is planned by the flat planner as a natural-order plan into the same flex_plan.
-static int build_with_blocks(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const int32_t *col_map, const int32_t *dst_map, unsigned flags,
-                             const flex_plan_tuning &tuning, std::vector<uint32_t> *sched_cache) {
-    const int32_t m = r1 - r0;
-    std::vector<uint32_t> *sched = nullptr, *colpos = nullptr;
-    PlanBuilder pre(p, A, r0, r1, col_map, dst_map, flags, tuning, sched_cache, 0);
-    int rc = pre.schedule_only(&sched, &colpos);
-    if (rc) return rc;
-    BlockKnobs kn;
-    const int32_t rd = tuning.block_rounds;
-    if (rd == 1 || rd == 2 || rd == 4 || rd == 8) kn.rounds = static_cast<uint32_t>(rd);
-    else if (rd != 0) return FLEX_ERR_INVALID;
-    if (tuning.block_panel_rows) {
-        if (tuning.block_panel_rows % 8 != 0 || tuning.block_panel_rows > static_cast<int32_t>(kBkPanelMax)) return FLEX_ERR_INVALID;
-        kn.panel_rows = static_cast<uint32_t>(tuning.block_panel_rows);
-    }
-    if (tuning.block_thr) kn.thr = static_cast<uint32_t>(tuning.block_thr);
-    else kn.thr = 3;  // measured: thr 3 is 1-2 % ahead of 2 on the amazon shapes (fewer panels, less padding), level on reddit
-    const double avg = m > 0 ? static_cast<double>(A->rowPtr[r1] - A->rowPtr[r0]) / m : 0.0;
-    // a slot may be about three average rows long before its row is spread over 2 / 4 / 8 slots (the wave that holds it is
-    // evened out against the others by the planner's longest-processing-time deal)
-    kn.cap = tuning.block_cap ? static_cast<uint32_t>(std::min<int32_t>(tuning.block_cap, 60000)) : static_cast<uint32_t>(std::clamp(3.0 * avg, 64.0, 4096.0));
-    kn.min_last_panel = std::min<uint32_t>(64, kn.panel_rows / 4);
-    BlockImage img;
-    std::vector<uint32_t> rest;
-    const uint32_t row_bytes32 = static_cast<uint32_t>(p->ldb) * 4u;
-    if ((rc = build_blocks(A, *sched, *colpos, col_map, dst_map, r0, row_bytes32, kn, img, rest))) return rc;
-    // upload the block image
-    if ((rc = upload(&p->d_bk_hdr, img.hdr, &p->device_bytes))) return rc;
-    if ((rc = upload(&p->d_bk_wstart, img.wstart, &p->device_bytes))) return rc;
-    if ((rc = upload(&p->d_bk_cnt, img.cnt, &p->device_bytes))) return rc;
-    if ((rc = upload(&p->d_bk_hcol, img.hcol, &p->device_bytes))) return rc;
-    if ((rc = upload(&p->d_bk_brow, img.brow, &p->device_bytes))) return rc;
-    if ((rc = upload(&p->d_bk_grp, img.grp, &p->device_bytes))) return rc;
-    if ((rc = upload(&p->d_bk_rec, img.rec, &p->device_bytes))) return rc;
-    p->bk_blocks = img.n_blocks;
-    p->bk_rounds = img.rounds;
-    p->bk_panel_rows = img.panel_rows;
-    p->bk_rows = img.rows;
-    p->bk_nnz = img.nnz;
-    p->bk_hot_nnz = img.hot_nnz;
-    p->bk_hot_cols = img.hot_cols;
-    p->bk_panels = img.panels;
-    p->bk_records = static_cast<int64_t>(img.rec.size());
-    p->bk_ablate = static_cast<uint32_t>(tuning.block_ablate);
-    img = BlockImage{};
-    // the rows that stay flat, as a CSR of their own (schedule order) with the C row of each
-    const size_t m_rest = rest.size();
-    std::vector<uint32_t> rp(m_rest + 1, 0u);
-    std::vector<int32_t> dst(m_rest + 1, 0);
-    for (size_t i = 0; i < m_rest; ++i) {
-        const uint32_t r = (*sched)[rest[i]];
-        rp[i + 1] = rp[i] + (A->rowPtr[r + 1] - A->rowPtr[r]);
-        dst[i] = dst_map ? dst_map[r] : static_cast<int32_t>(r) - r0;
-    }
-    std::vector<uint32_t> cc(std::max<size_t>(rp[m_rest], 1));
-    std::vector<float> vv(std::max<size_t>(rp[m_rest], 1));
-    for (size_t i = 0; i < m_rest; ++i) {
-        const uint32_t r = (*sched)[rest[i]];
-        std::copy(A->col + A->rowPtr[r], A->col + A->rowPtr[r + 1], cc.begin() + rp[i]);
-        std::copy(A->vals + A->rowPtr[r], A->vals + A->rowPtr[r + 1], vv.begin() + rp[i]);
-    }
-    const flex_csr A_rest{static_cast<int32_t>(m_rest), A->n, static_cast<int64_t>(rp[m_rest]), rp.data(), cc.data(), vv.data()};
-    const unsigned order = flags & FLEX_ORDER_MASK;
-    flex_plan_tuning t2 = tuning;
-    t2.mfma = 2;  // the dense-tile route and the block route do not combine (yet)
-    rc = PlanBuilder(p, &A_rest, 0, static_cast<int32_t>(m_rest), col_map, dst.data(), (flags & ~FLEX_ORDER_MASK) | FLEX_ORDER_NATURAL, t2, nullptr, 0).run();
-    if (rc) return rc;
-    if (flags & FLEX_PLAN_STATS) {  // the LDS-level reuse figures describe the WHOLE matrix, not the rows left to the flat planner
-        p->lds_hot[0] = 100.0 * estimate_hot_share(A, *sched, 480, 2, 4, &p->lds_u[0]);
-        p->lds_hot[1] = 100.0 * estimate_hot_share(A, *sched, 480, 4, 4, &p->lds_u[1]);
-        p->stats.lds_hot_pct_2 = p->lds_hot[0];
-        p->stats.lds_hot_pct_4 = p->lds_hot[1];
-        p->stats.lds_u_2 = p->lds_u[0];
-        p->stats.lds_u_4 = p->lds_u[1];
-    }
-    p->order = order;
-    p->c_rows = dst_map ? A->m : m;
-    flex_plan_tuning &u = p->tuning;
-    u.blocks = 1;
-    u.block_rounds = static_cast<int32_t>(kn.rounds);
-    u.block_panel_rows = static_cast<int32_t>(kn.panel_rows);
-    u.block_thr = static_cast<int32_t>(kn.thr);
-    u.block_cap = static_cast<int32_t>(kn.cap);
-    return FLEX_OK;
-}
-
 int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const int32_t *col_map, const int32_t *dst_map, unsigned flags,
                const flex_plan_tuning &tuning, std::vector<uint32_t> *sched_cache, int force_G) try {
-    // Row blocks need the float4 path's shapes, 32-bit B offsets, and no forced tile width (autotune candidates stay flat).
-    const bool block_shapes = p->k % 4 == 0 && p->ldb % 4 == 0 && p->ldc % 4 == 0 &&
+    // Hot blocks need the float4 path's shapes, 32-bit B offsets, whole 64-column tiles' worth of k, and no forced tile width
+    // (autotune candidates stay flat).
+    const bool block_shapes = p->k % 4 == 0 && p->k >= 64 && p->ldb % 4 == 0 && p->ldc % 4 == 0 &&
                               static_cast<uint64_t>(A->n) * static_cast<uint64_t>(p->ldb) * 4u <= (uint64_t(1) << 32);
     const bool can_block = block_shapes && force_G == 0 && r1 > r0 && tuning.mfma != 1 && tuning.two_d != 1 && tuning.blocks != 2;
-    if (tuning.blocks == 1 && can_block) return build_with_blocks(p, A, r0, r1, col_map, dst_map, flags, tuning, sched_cache);
-    // The rule (tuning.blocks = 0), from what was measured on MI355X: the block kernel moves the same bytes over
-    // the fabric as the flat one, so it only pays where the flat kernel is NOT bound by its L2 misses -- a large share of the
-    // nonzeros sits in columns that a block of 480 rows uses three times or more -- and where there are enough blocks to keep 256
-    // CUs busy to the end (one workgroup per CU): amazon shape without uniformly random edges 7.65 -> 6.53 ms (hot share 0.77), its
-    // preset 8.24 -> 8.34 (0.62), reddit shapes 0.86x (564 blocks).  The look costs one sort of every 16th block's columns.
+    bool want_blocks = tuning.blocks == 1 && can_block;
+    std::vector<uint32_t> local_cache;
+    // The rule (tuning.blocks = 0): the split pays where a sizeable share of the nonzeros has reuse inside a block of a few hundred
+    // schedule-consecutive rows AND the launch is long enough for a second kernel's start-up and tail to disappear in it.  The look
+    // costs one sort of every 16th block's columns; the schedule it needs is computed once and handed on.
     const int64_t nnz_in = static_cast<int64_t>(A->rowPtr[r1]) - A->rowPtr[r0];
-    if (tuning.blocks == 0 && can_block && static_cast<int64_t>(r1 - r0) >= 480 * 2048 && nnz_in >= 48ll * (r1 - r0)) {
-        std::vector<uint32_t> local_cache;
-        std::vector<uint32_t> *cache = sched_cache ? sched_cache : &local_cache;
+    if (tuning.blocks == 0 && can_block && static_cast<int64_t>(r1 - r0) >= 120000 && nnz_in >= 32ll * (r1 - r0)) {
+        if (!sched_cache) sched_cache = &local_cache;
         std::vector<uint32_t> *sched = nullptr, *colpos = nullptr;
         int rc;
         {
-            PlanBuilder pre(p, A, r0, r1, col_map, dst_map, flags, tuning, cache, 0);
+            PlanBuilder pre(p, A, r0, r1, col_map, dst_map, flags, tuning, sched_cache, 0);
             if ((rc = pre.schedule_only(&sched, &colpos))) return rc;
         }
-        const double share = estimate_hot_share(A, *cache, 480, 3, 16);
-        if (plan_timing_enabled()) std::fprintf(stderr, "plan: hot share of 480-row blocks (thr 3, every 16th) %.3f\n", share);
-        if (share >= 0.72) return build_with_blocks(p, A, r0, r1, col_map, dst_map, flags, tuning, cache);
-        return PlanBuilder(p, A, r0, r1, col_map, dst_map, flags, tuning, cache, force_G).run();  // the schedule is computed once
+        const double share = estimate_hot_share(A, *sched_cache, 480, 2, 16);
+        if (plan_timing_enabled()) std::fprintf(stderr, "plan: hot share of 480-row blocks (thr 2, every 16th) %.3f\n", share);
+        want_blocks = share >= 0.5;
     }
-    return PlanBuilder(p, A, r0, r1, col_map, dst_map, flags, tuning, sched_cache, force_G).run();
+    return PlanBuilder(p, A, r0, r1, col_map, dst_map, flags, tuning, sched_cache, force_G, want_blocks).run();
 } catch (const std::bad_alloc &) {  // any host allocation of any stage
     return FLEX_ERR_NOMEM;
 }

@@ -243,21 +243,20 @@ int flex_plan_self_check(const flex_plan *p) try {
             if (col >= static_cast<uint64_t>(p->n) || (p->off32 && o % row_bytes != 0)) return FLEX_ERR_FORMAT;
         }
     }
-    // row blocks: the block table tiles hcol / cnt / the record streams, every wave's counts add up to its stream, every record
-    // names a valid B row (cold phase) or a row of its panel buffer (panel phases; padding = the row of zeros with value 0), the
-    // slots of a long row are aligned and agree, and every C row a block owns is written by exactly one slot
+    // hot blocks: the block table tiles hcol / cnt / the record streams, every wave's run counts add up to its stream and no run is
+    // longer than one DPP row, every record names a row of its panel buffer (padding = the row of zeros with value 0), every staged
+    // B row is valid, and every C row that a block adds to is a row the flat plan writes and is named by one slot only
     if (p->bk_blocks) {
         const uint32_t nb = p->bk_blocks, rounds = p->bk_rounds, P = p->bk_panel_rows, RB = rounds * kBkRowsPerRound;
-        if ((rounds != 1 && rounds != 2 && rounds != 4 && rounds != 8) || P == 0 || P % 8 != 0 || P > kBkPanelMax || !p->off32) return FLEX_ERR_FORMAT;
+        if ((rounds != 2 && rounds != 4 && rounds != 8) || P == 0 || P % 4 != 0 || P > kBkPanelMax || !p->off32) return FLEX_ERR_FORMAT;
         std::vector<uint4> hdr(nb);
         std::vector<uint2> wstart(static_cast<size_t>(nb) * kBkWaves), brec(static_cast<size_t>(p->bk_records));
-        std::vector<uint32_t> brow(static_cast<size_t>(nb) * RB), grp(static_cast<size_t>(nb) * rounds * kBkWaves);
+        std::vector<uint32_t> brow(static_cast<size_t>(nb) * RB);
         if (cur != p->device) FLEX_HIP_TRY(hipSetDevice(p->device));
         bool ok_b = down(hdr.data(), p->d_bk_hdr, hdr.size() * sizeof(uint4)) && down(wstart.data(), p->d_bk_wstart, wstart.size() * sizeof(uint2)) &&
-                    down(brec.data(), p->d_bk_rec, brec.size() * sizeof(uint2)) && down(brow.data(), p->d_bk_brow, brow.size() * 4) &&
-                    down(grp.data(), p->d_bk_grp, grp.size() * 4);
-        const uint64_t n_cnt = static_cast<uint64_t>(hdr.back().z) + static_cast<uint64_t>(hdr.back().w) * kBkWaves;
-        const uint64_t n_hcol = static_cast<uint64_t>(hdr.back().y) + static_cast<uint64_t>(hdr.back().x & 0x7FFFFFFFu) * P;
+                    down(brec.data(), p->d_bk_rec, brec.size() * sizeof(uint2)) && down(brow.data(), p->d_bk_brow, brow.size() * 4);
+        uint64_t n_cnt = 0, n_hcol = 0;
+        for (const uint4 &h : hdr) n_cnt += static_cast<uint64_t>(h.w) * kBkWaves, n_hcol += static_cast<uint64_t>(h.x) * P;
         std::vector<uint32_t> cnt(static_cast<size_t>(n_cnt)), hcol(static_cast<size_t>(n_hcol));
         ok_b = ok_b && down(cnt.data(), p->d_bk_cnt, cnt.size() * 4) && down(hcol.data(), p->d_bk_hcol, hcol.size() * 4);
         if (cur != p->device) (void)hipSetDevice(cur);
@@ -265,13 +264,15 @@ int flex_plan_self_check(const flex_plan *p) try {
         for (uint32_t o : hcol)
             if (o % row_bytes != 0 || o / row_bytes >= static_cast<uint64_t>(p->n)) return FLEX_ERR_FORMAT;
         uint64_t at_hcol = 0, at_cnt = 0, at_step = 0;
-        int64_t panels = 0, owned = 0;
+        int64_t panels = 0, real = 0;
+        std::vector<uint8_t> added(static_cast<size_t>(p->c_rows), 0);
         for (uint32_t b = 0; b < nb; ++b) {
-            uint4 h = hdr[b];
-            const bool has_hubs = (h.x >> 31) != 0;
-            h.x &= 0x7FFFFFFFu;
-            const uint32_t n_ph = h.x + 1;
-            if (h.y != at_hcol || h.z != at_cnt || h.w != (n_ph * rounds + 1) / 2 || n_ph * rounds > kBkMaxCounts || h.y % 4 != 0) return FLEX_ERR_FORMAT;
+            const uint4 h = hdr[b];
+            if (h.x == 0) {
+                if (h.w != 0) return FLEX_ERR_FORMAT;
+            } else if (h.y != at_hcol || h.z != at_cnt || h.w != (h.x * rounds + 1) / 2 || h.x * rounds + rounds > kBkMaxCounts || h.y % 4 != 0) {
+                return FLEX_ERR_FORMAT;
+            }
             at_hcol += static_cast<uint64_t>(h.x) * P;
             at_cnt += static_cast<uint64_t>(h.w) * kBkWaves;
             panels += h.x;
@@ -279,19 +280,18 @@ int flex_plan_self_check(const flex_plan *p) try {
                 const uint2 ws = wstart[static_cast<size_t>(b) * kBkWaves + w];
                 if (ws.x != at_step) return FLEX_ERR_FORMAT;
                 uint64_t pos = static_cast<uint64_t>(ws.x) * kBkSlots, steps = 0;
-                for (uint32_t idx = 0; idx < n_ph * rounds; ++idx) {
+                for (uint32_t idx = 0; idx < h.x * rounds; ++idx) {
                     const uint32_t word = cnt[h.z + static_cast<size_t>(w) * h.w + idx / 2];
                     const uint32_t n = (idx & 1) ? word >> 16 : word & 0xFFFFu;
-                    const bool cold = idx < rounds;
-                    if (pos + static_cast<uint64_t>(n) * kBkSlots > brec.size()) return FLEX_ERR_FORMAT;
+                    if (n > kBkRunMax || pos + static_cast<uint64_t>(n) * kBkSlots > brec.size()) return FLEX_ERR_FORMAT;
                     for (uint64_t q = 0; q < static_cast<uint64_t>(n) * kBkSlots; ++q) {
                         const uint2 r = brec[pos + q];
-                        if (cold) {
-                            if (r.x % row_bytes != 0 || r.x / row_bytes >= static_cast<uint64_t>(p->n)) return FLEX_ERR_FORMAT;
-                        } else if (r.x == kBkZeroRow || r.x == kBkZeroRow + kBkRowBytes) {
+                        if (r.x == kBkZeroRow) {
                             if (r.y != 0) return FLEX_ERR_FORMAT;
                         } else if (r.x % kBkRowBytes != 0 || r.x / kBkRowBytes >= P) {
                             return FLEX_ERR_FORMAT;
+                        } else {
+                            ++real;
                         }
                     }
                     pos += static_cast<uint64_t>(n) * kBkSlots;
@@ -300,47 +300,13 @@ int flex_plan_self_check(const flex_plan *p) try {
                 if (steps != ws.y) return FLEX_ERR_FORMAT;
                 at_step += steps;
             }
-            // hub rows: g >= 2 whole groups on g different waves, parts 0..g-1 each exactly once, consecutive scratch slots inside a panel buffer
-            uint32_t hub_groups = 0;
-            for (uint32_t g = 0; g < RB / kBkSlots; ++g) {
-                const uint32_t gi = grp[static_cast<size_t>(b) * (RB / kBkSlots) + g];
-                if (gi == 0) continue;
-                const uint32_t part = gi & 0xFFu, ng = (gi >> 8) & 0xFFu, base = gi >> 16;
-                const uint32_t e0 = brow[static_cast<size_t>(b) * RB + g * kBkSlots];
-                if (!has_hubs || ng < 2 || ng > kBkWaves || part >= ng || (base + ng - 1) * kBkRowBytes > kBkZeroRow || (e0 >> 29) != 3 || (e0 & kBkEmptyRow) == kBkEmptyRow) return FLEX_ERR_FORMAT;
-                ++hub_groups;
-                if (part != 0) continue;
-                uint32_t seen_parts = 1, wave_mask = 1u << (g % kBkWaves);
-                for (uint32_t g2 = 0; g2 < RB / kBkSlots; ++g2) {
-                    const uint32_t gj = grp[static_cast<size_t>(b) * (RB / kBkSlots) + g2];
-                    if (g2 == g || gj == 0 || (gj >> 16) != base || brow[static_cast<size_t>(b) * RB + g2 * kBkSlots] != e0) continue;
-                    if (((gj >> 8) & 0xFFu) != ng || (wave_mask >> (g2 % kBkWaves)) & 1u) return FLEX_ERR_FORMAT;
-                    wave_mask |= 1u << (g2 % kBkWaves);
-                    seen_parts |= 1u << (gj & 0xFFu);
-                }
-                if (seen_parts != (1u << ng) - 1u) return FLEX_ERR_FORMAT;
+            for (uint32_t s = 0; s < RB; ++s) {
+                const uint32_t row = brow[static_cast<size_t>(b) * RB + s];
+                if (row == kBkEmptyRow) continue;
+                if (row >= p->c_rows || !written[row] || added[row]++) return FLEX_ERR_FORMAT;
             }
-            if (has_hubs != (hub_groups != 0)) return FLEX_ERR_FORMAT;
-            for (uint32_t g = 0; g < RB / kBkSlots; ++g)
-                for (uint32_t s0 = 0; s0 < kBkSlots;) {
-                    const uint32_t e = brow[static_cast<size_t>(b) * RB + g * kBkSlots + s0];
-                    const uint32_t v = 1u << (e >> 29), row = e & kBkEmptyRow;
-                    if (s0 % v != 0) return FLEX_ERR_FORMAT;
-                    for (uint32_t s = 1; s < v; ++s)
-                        if (brow[static_cast<size_t>(b) * RB + g * kBkSlots + s0 + s] != e) return FLEX_ERR_FORMAT;
-                    const uint32_t gi = grp[static_cast<size_t>(b) * (RB / kBkSlots) + g];
-                    if (row != kBkEmptyRow && gi != 0 && (gi & 0xFFu) != 0) {
-                        if (row >= p->c_rows) return FLEX_ERR_FORMAT;  // a later part of a hub row: part 0 is the writer
-                    } else if (row != kBkEmptyRow) {
-                        if (row >= p->c_rows || written[row]++) return FLEX_ERR_FORMAT;
-                        ++owned;
-                    } else if (v != 1) {
-                        return FLEX_ERR_FORMAT;
-                    }
-                    s0 += v;
-                }
         }
-        if (at_step * kBkSlots != brec.size() || at_hcol != hcol.size() || at_cnt != cnt.size() || panels != p->bk_panels || owned != p->bk_rows) return FLEX_ERR_FORMAT;
+        if (at_step * kBkSlots != brec.size() || at_hcol != hcol.size() || at_cnt != cnt.size() || panels != p->bk_panels || real != p->bk_hot_nnz) return FLEX_ERR_FORMAT;
     }
     // a full plan (not a row shard of a mapped matrix) writes every row of C
     if (p->c_rows == p->m)

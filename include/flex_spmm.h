@@ -147,15 +147,16 @@ typedef struct flex_plan_tuning {
     int32_t lds_extra;       /* bytes of idle LDS per workgroup (occupancy throttle; multiple of 16) */
     int32_t host_threads;    /* host threads of this call (rule: flex_set_host_threads, else the core count, at most 32) */
     flex_cluster_tuning cluster;
-    /* the row-block path (LDS-staged B panels) */
-    int32_t blocks;           /* 1: rows go to row blocks (one workgroup per block, hot B rows staged in LDS), 2: never (rule: on very
-                                 large inputs -- >= 983 040 rows of average degree >= 48 -- when a sampled look finds >= 72 % of the
-                                 nonzeros in columns that a block of 480 rows uses three times or more; needs 16-byte aligned operands) */
-    int32_t block_rounds;     /* rows per slot: 1, 2, 4 or 8; a block is rounds x 120 row slots (4) */
-    int32_t block_panel_rows; /* B rows per LDS panel: a multiple of 8, at most 480 (480) */
+    /* the hot-block path (the matrix is SPLIT: nonzeros with reuse inside a block of rows are multiplied out of LDS-staged B panels by
+       their own kernel after the flat kernel has done the rest) */
+    int32_t blocks;           /* 1: split, 2: never (rule: k >= 64, >= 120 000 rows of average degree >= 32, and a sampled look finds
+                                 >= 50 % of the nonzeros in columns that a block of 480 rows uses twice or more; needs 16-byte aligned
+                                 operands: flex_spmm returns FLEX_ERR_UNSUPPORTED for others) */
+    int32_t block_rounds;     /* rows per slot: 2, 4 or 8; a block is rounds x 60 rows (8; 4 / 2 while there are few blocks per CU) */
+    int32_t block_panel_rows; /* B rows per LDS panel: a multiple of 4, at most 304 (304) */
     int32_t block_thr;        /* a column is hot (staged) when at least this many nonzeros of the block use it (2) */
-    int32_t block_cap;        /* records per slot beyond which a row takes 2 / 4 / 8 slots; rows beyond 8 x cap stay flat */
-    int32_t block_ablate;     /* timing-only experiments, the RESULT IS WRONG: 1 no panel staging, 2 no panel-phase work, 4 no cold-phase work */
+    int32_t block_cap;        /* rows longer than this take no slot: all of their nonzeros stay with the flat kernel (6 x the average degree) */
+    int32_t block_ablate;     /* timing-only experiments, the RESULT IS WRONG: 1 no panel staging, 2 no panel work */
     int32_t tile_group;       /* multi-tile launches: workgroups per group -- every XCD's slice of the schedule is walked group by group, all
                                  column tiles of a group back to back, so that a group's records are re-read from the Infinity Cache rather
                                  than from HBM (0 = rule; 1 = off: one pass over the whole schedule per tile) */
@@ -214,14 +215,14 @@ typedef struct flex_plan_info {
     int64_t n_tiles;      /* dense 32x32 tiles of A routed to the MFMA kernel (0: the vector kernel does everything) */
     int64_t tile_nnz;     /* nonzeros held by those tiles */
     int64_t n_records;    /* (col,val) records the vector kernel streams per column tile: nnz - tile_nnz + padding */
-    /* the row-block path (0 everywhere when the plan has no blocks) */
-    int64_t n_blocks;         /* row blocks: one workgroup each */
-    int64_t block_rows;       /* rows they own (the rest -- empty rows, hubs -- stay with the vector kernel) */
+    /* the hot-block path (0 everywhere when the plan has no blocks) */
+    int64_t n_blocks;         /* blocks: one workgroup each (per 64-column tile) */
+    int64_t block_rows;       /* rows that hold a slot in a block (empty and very long rows hold none) */
     int64_t block_nnz;        /* nonzeros of those rows */
-    int64_t block_hot_nnz;    /* ... that read their B row from an LDS panel */
+    int64_t block_hot_nnz;    /* nonzeros in the block image: they read their B row from an LDS panel and are NOT in the flat plan's records */
     int64_t block_hot_cols;   /* B rows staged, summed over blocks: block_hot_nnz / block_hot_cols = u, the reuse of a staged row */
     int64_t block_panels;     /* panels staged per column tile, summed over blocks */
-    int64_t block_records;    /* records the block kernel streams per column tile: block_nnz + padding */
+    int64_t block_records;    /* records the hot kernel streams per 64-column tile: block_hot_nnz + padding */
 } flex_plan_info;
 int flex_plan_get_info(const flex_plan *plan, flex_plan_info *out);
 

@@ -231,32 +231,42 @@ def test_descriptor_without_the_range_flag_refuses_a_range(sim):
     L.flex_plan_destroy(h)
 
 
-@pytest.mark.parametrize("rounds,panel_rows,thr,cap", [(4, 480, 2, 0), (1, 64, 2, 40), (2, 128, 3, 24), (8, 480, 4, 0), (4, 8, 2, 16)])
-def test_row_block_plans_are_partitions(sim, rounds, panel_rows, thr, cap):
-    """The row-block route (LDS-staged B panels): rows go to blocks of rounds x 120 slots, long rows take 2 / 4 / 8 aligned slots,
-    empty rows and rows beyond 8 x cap stay with the flat planner; the device image must be a partition of the work
-    (flex_plan_self_check reads the block tables and every record stream back) for every shape of the knobs."""
+@pytest.mark.parametrize("rounds,panel_rows,thr,cap", [(8, 304, 2, 0), (2, 64, 2, 40), (4, 128, 3, 24), (8, 300, 4, 0), (4, 8, 2, 16)])
+def test_hot_block_plans_are_partitions(sim, rounds, panel_rows, thr, cap):
+    """The hot-block route (the matrix is split: nonzeros with reuse inside a block of rounds x 60 rows go to LDS-staged B panels,
+    the rest -- and every row longer than `cap` -- stays with the flat planner): the device image must be a partition of the work
+    (flex_plan_self_check reads the block tables and every record stream back; flat records + hot records = every nonzero) for
+    every shape of the knobs."""
     a = random_csr(9000, 9000, 20, seed=31, long_rows={5: 8000, 77: 1200, 4000: 300, 8999: 150}, empty_frac=0.05)
     g = flex_amd.synth_graph(n=12000, nnz=12000 + 2 * 240000, community=300, p_in=0.6, p_near=0.25, seed=12)
     knobs = {"blocks": 1, "block_rounds": rounds, "block_panel_rows": panel_rows, "block_thr": thr, "block_cap": cap}
-    for mat, order, k in ((a, flex_amd.FLEX_ORDER_NATURAL, 128), (g, flex_amd.FLEX_ORDER_CLUSTER, 32), (g, flex_amd.FLEX_ORDER_RCM, 100)):
+    for mat, order, k in ((a, flex_amd.FLEX_ORDER_NATURAL, 128), (g, flex_amd.FLEX_ORDER_CLUSTER, 64), (g, flex_amd.FLEX_ORDER_RCM, 100)):
         p = flex_amd.Plan(mat, k, order=order, tuning=knobs)
         p.self_check()
         i, t = p.info(), p.tuning()
-        assert i["n_blocks"] > 0 and t["blocks"] == 1 and t["block_rounds"] == rounds and t["block_panel_rows"] == panel_rows
-        assert 0 < i["block_rows"] <= mat.m and i["block_nnz"] <= mat.nnz and i["block_records"] >= i["block_nnz"]
+        assert t["blocks"] == 1 and t["block_rounds"] == rounds and t["block_panel_rows"] == panel_rows and t["block_thr"] == thr
+        if mat is g:
+            assert i["n_blocks"] > 0
+        assert i["block_rows"] <= mat.m and i["block_nnz"] <= mat.nnz and i["block_records"] >= i["block_hot_nnz"]
         assert i["block_hot_nnz"] <= i["block_nnz"] and i["block_hot_cols"] <= i["block_panels"] * panel_rows
-        assert i["n_records"] + i["block_records"] >= mat.nnz  # flat part + blocks hold every nonzero
+        assert i["n_records"] >= mat.nnz - i["block_hot_nnz"]  # the flat plan holds exactly the nonzeros the blocks do not (+ padding)
+        assert i["n_tasks"] >= mat.m  # ... and still every row: the flat kernel writes all of C, the hot kernel adds to it
         if mat is g and order == flex_amd.FLEX_ORDER_CLUSTER and rounds >= 4 and thr == 2 and panel_rows >= 64:
             assert i["block_hot_nnz"] > 0.3 * mat.nnz  # the planted communities are found as hot columns
+    # a row longer than the cap holds no slot: with a tiny cap nothing is left for the blocks
+    assert flex_amd.Plan(g, 128, order=flex_amd.FLEX_ORDER_CLUSTER, tuning=dict(knobs, block_cap=1)).info()["block_hot_nnz"] == 0
     # shards and mapped plans go through the route too
     vo, gp = flex_amd.perm_csr(g, flex_amd.order_cluster(g))
     flex_amd.Plan(gp, 128, vo_mp=vo, tuning=knobs).self_check()
     pb = flex_amd.Plan(gp, 64, rows=(1000, 7000), col_map=vo, tuning=knobs)
     pb.self_check()
     assert pb.info()["block_rows"] <= 6000
-    # shapes the block kernel does not take fall back to the flat plan silently
-    assert flex_amd.Plan(g, 7, tuning=knobs).info()["n_blocks"] == 0
+    # shapes the hot kernel does not take (k below one 64-column tile, k % 4 != 0) get a flat plan silently
+    assert flex_amd.Plan(g, 7, tuning=knobs).info()["n_blocks"] == 0 and flex_amd.Plan(g, 32, tuning=knobs).info()["n_blocks"] == 0
+    # nonsense is refused
+    for bad in ({"block_rounds": 3}, {"block_panel_rows": 6}, {"block_panel_rows": 308}):
+        with pytest.raises(flex_amd.FlexError):
+            flex_amd.Plan(g, 128, tuning=dict(knobs, **bad))
     # the same image for any number of host threads
     sim.hostsim_upload_hash.restype = C.c_uint64
     sim.hostsim_upload_hash.argtypes = [C.c_int]

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""tools/probe_blocks.py [workload k ...] -- the row-block path (LDS-staged B panels) against the flat kernel on one workload:
-launch time, what the block image looks like (hot share, u, panels, padding), over the knobs given as BLOCK_SWEEP
-("rounds:panel_rows:thr:cap,..."; default a small grid)."""
+"""tools/probe_blocks.py [workload k ...] -- the hot-block path (the matrix split: LDS-staged B panels for the nonzeros with reuse
+inside a block of rows, the flat kernel for the rest) against the flat kernel alone on one workload: launch time, what the block
+image looks like (hot share, u, panels, padding), over the knobs given as BLOCK_SWEEP ("rounds:panel_rows:thr:cap[:ablate],...";
+default a small grid).  ablate 2 = no panel work (what the flat part + staging cost), 3 = neither staging nor work."""
 import os
 import sys
 import time
@@ -16,7 +17,7 @@ if os.environ.get("PROBE_LIB"):  # an experiment build of the library (make -C f
 from tools._timing import timeit  # noqa: E402
 
 args = sys.argv[1:] or ["reddit", "128"]
-grid = os.environ.get("BLOCK_SWEEP", "4:480:2:0,4:480:3:0,2:480:2:0,8:480:2:0,4:256:2:0")  # a 5th field = block_ablate (timing only)
+grid = os.environ.get("BLOCK_SWEEP", "8:304:2:0,8:304:3:0,4:304:2:0,8:304:2:0:2,8:304:2:0:3")  # a 5th field = block_ablate (timing only)
 for name, k in zip(args[0::2], (int(x) for x in args[1::2])):
     gen = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in os.environ.get("GEN", "").split(",") if kv}  # e.g. GEN=p_in=0.75,p_near=0.25
     if gen:
@@ -47,6 +48,6 @@ for name, k in zip(args[0::2], (int(x) for x in args[1::2])):
         t = timeit(pb, B, C, reps)
         err = float((C - ref).abs().max())
         print(f"{name} k={k} rounds={rounds} panel={prow} thr={thr} cap={pb.tuning()['block_cap']}{' ABLATE=' + str(abl) if abl else ''}: {t:8.1f} us ({t_flat / t:.2f}x)  blocks {i['n_blocks']} rows {100 * i['block_rows'] / ap.m:.1f} % "
-              f"nnz {100 * i['block_nnz'] / ap.nnz:.1f} % hot {100 * i['block_hot_nnz'] / max(i['block_nnz'], 1):.1f} % u={i['block_hot_nnz'] / max(i['block_hot_cols'], 1):.2f} "
-              f"panels/block {i['block_panels'] / max(i['n_blocks'], 1):.1f} pad {100 * (i['block_records'] / max(i['block_nnz'], 1) - 1):.1f} % plan {tp:.1f} s  max|diff vs flat| {err:.2e}", flush=True)
+              f"hot {100 * i['block_hot_nnz'] / ap.nnz:.1f} % of nnz, u={i['block_hot_nnz'] / max(i['block_hot_cols'], 1):.2f} "
+              f"panels/block {i['block_panels'] / max(i['n_blocks'], 1):.1f} pad {100 * (i['block_records'] / max(i['block_hot_nnz'], 1) - 1):.1f} % flat records {i['n_records']} plan {tp:.1f} s  max|diff vs flat| {err:.2e}", flush=True)
         pb.destroy()
