@@ -107,7 +107,8 @@ __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_hot_kernel(BlockView
     const uint32_t blk = v.xcd_remap ? (blockIdx.x % kXcds) * cpx + blockIdx.x / kXcds : blockIdx.x;
     if (blk >= v.n_blocks) return;  // the whole workgroup: no barrier has been reached
     const uint4 hdr = v.hdr[blk];
-    const uint32_t np = hdr.x;
+    const uint32_t np = hdr.x & 0x7FFFFFFFu;
+    const bool chains = (hdr.x >> 31) != 0;  // some row of the block has several parts: one more barrier, they meet in LDS
     if (np == 0) return;  // a block without hot columns (the whole workgroup)
     const int k = v.k;
     // One workgroup = one (block, 64-column tile).  Tiles are the SLOW grid dimension: the hardware dispatches all blocks of
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_hot_kernel(BlockView
             if (p + 2 < np) dma_hcol(lds, hcol + static_cast<uint64_t>(p + 2) * P, P, p & 1, lane);
             loader_barrier();  // consumers are done with panel p; panel p+1 has landed
         }
+        if (chains) loader_barrier();
         return;
     }
 
@@ -238,6 +240,33 @@ __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_hot_kernel(BlockView
         BK_STAMP(2);
         consumer_barrier();
         BK_STAMP(3);
+    }
+    // A long row's parts: every later part leaves its sum (and the slot of the part after it) in LDS -- the panel buffers are free
+    // now -- and after one more barrier the owner adds them in chain order: a fixed order, so the result is reproducible.
+    if (chains) {  // workgroup-uniform
+        uint32_t link[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) link[r] = v.link[((static_cast<uint64_t>(blk) * ROUNDS + r) * kBkWaves + w) * kBkSlots + slot];
+        uint32_t *nxt = reinterpret_cast<uint32_t *>(lds + kBkLdsHcol);  // [rounds x 60] next part + 1
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            if (link[r] & kBkLinkPart) {
+                const uint32_t me = (static_cast<uint32_t>(r) * kBkWaves + w) * kBkSlots + slot;
+                *reinterpret_cast<v4f *>(lds + me * kBkRowBytes + l16 * 16) = acc[r];
+                if (l16 == 0) nxt[me] = link[r] & 0xFFFFu;
+            }
+        }
+        consumer_barrier();
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            if (link[r] & kBkLinkOwner) {
+                uint32_t hops = 0;  // a chain has fewer links than the block has slots: the bound only keeps a damaged image from spinning
+                for (uint32_t n = link[r] & 0xFFFFu; n != 0 && n <= ROUNDS * kBkRowsPerRound && hops < ROUNDS * kBkRowsPerRound; n = nxt[n - 1], ++hops) {
+                    const v4f o = *reinterpret_cast<const v4f *>(lds + (n - 1) * kBkRowBytes + l16 * 16);
+                    acc[r] += o;
+                }
+            }
+        }
     }
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r)

@@ -10,7 +10,9 @@
 // planner through `hot_mask`, and so is everything awkward: rows too long for one slot, the 17th and later nonzeros of one
 // row in one panel, columns beyond the panel budget.
 //
-//   walk the schedule       rows of 1 .. cap nonzeros take one slot each, R to a block; longer and empty rows take none
+//   walk the schedule       a row of len nonzeros takes ceil(len / cap) slots (its PARTS: each accumulates a share of the row's hot
+//                           nonzeros, the first one -- the OWNER -- collects the others through LDS at the end of the tile and
+//                           writes the row); R slots to a block; empty rows and rows of more than R slots take none
 //   per block (parallel)    count column uses -> hot columns -> panels (in schedule order of the columns); every hot nonzero
 //                           becomes a record {byte offset inside the panel buffer, value} of (slot, panel);
 //                           slots with similar panel profiles are grouped 4 to a (wave, round), groups dealt to the 15 waves by
@@ -39,9 +41,10 @@ struct Entry {  // one nonzero of the block
 struct BlockOut {
     uint4 hdr{};
     std::vector<uint2> wstart;  // 15: {first step (block-relative), steps}
-    std::vector<uint32_t> cnt, hcol, brow;
+    std::vector<uint32_t> cnt, hcol, brow, link;
     std::vector<uint2> rec;
     int64_t hot_nnz = 0, nnz = 0, hot_cols = 0, rows = 0;
+    bool multi = false;  // some row of the block has several parts
 };
 
 }  // namespace
@@ -84,27 +87,49 @@ int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const st
     const uint32_t e_base = m > 0 ? A->rowPtr[r0] : 0u;
     const size_t nnz_in = m > 0 ? static_cast<size_t>(A->rowPtr[r0 + m] - e_base) : 0;
     hot_mask.assign(nnz_in, 0);
-    // ---- rows -> blocks (sequential: one pass over the row lengths)
-    std::vector<uint32_t> items;      // schedule positions of the rows that take a slot
+    // ---- rows -> items -> blocks (sequential: one pass over the row lengths)
+    struct Item {
+        uint32_t spos, v;  // schedule position of the row, slots it takes
+    };
+    std::vector<Item> items;
+    std::vector<uint32_t> blk_first;  // first item of each block (+ sentinel)
+    uint32_t used = RB;               // forces the first block open
     for (int64_t i = 0; i < m; ++i) {
         const uint32_t r = sched[i];
         const uint32_t len = A->rowPtr[r + 1] - A->rowPtr[r];
-        if (len > 0 && len <= kn.cap) items.push_back(static_cast<uint32_t>(i));
+        if (len == 0) continue;
+        const uint64_t v = (static_cast<uint64_t>(len) + kn.cap - 1) / kn.cap;
+        if (v > RB) continue;  // longer than a whole block of slots: stays flat
+        if (used + v > RB) {
+            blk_first.push_back(static_cast<uint32_t>(items.size()));
+            used = 0;
+        }
+        used += static_cast<uint32_t>(v);
+        items.push_back({static_cast<uint32_t>(i), static_cast<uint32_t>(v)});
     }
-    const int64_t nb = (static_cast<int64_t>(items.size()) + RB - 1) / RB;
-    if (nb <= 0) return FLEX_OK;
+    blk_first.push_back(static_cast<uint32_t>(items.size()));
+    const int64_t nb = static_cast<int64_t>(blk_first.size()) - 1;
+    if (nb <= 0 || items.empty()) return FLEX_OK;
     if (nb >= (int64_t(1) << 31)) return FLEX_ERR_UNSUPPORTED;
 
     std::vector<BlockOut> out(static_cast<size_t>(nb));
     parallel_chunks(nb, [&](int64_t b) {
         BlockOut &o = out[static_cast<size_t>(b)];
-        const uint32_t *it = items.data() + b * RB;
-        const uint32_t n_it = static_cast<uint32_t>(std::min<int64_t>(RB, static_cast<int64_t>(items.size()) - b * RB));
+        const Item *it = items.data() + blk_first[b];
+        const uint32_t n_it = blk_first[b + 1] - blk_first[b];
         o.rows = n_it;
+        // slots: item x holds slots [first_slot[x], first_slot[x] + v): its parts
+        std::vector<uint32_t> first_slot(n_it);
+        uint32_t n_sl = 0;
+        for (uint32_t x = 0; x < n_it; ++x) {
+            first_slot[x] = n_sl;
+            n_sl += it[x].v;
+            if (it[x].v > 1) o.multi = true;
+        }
         // ---- the block's nonzeros, and how often each column is used
         std::vector<Entry> ent;
         for (uint32_t x = 0; x < n_it; ++x) {
-            const uint32_t r = sched[it[x]];
+            const uint32_t r = sched[it[x].spos];
             for (uint32_t e = A->rowPtr[r]; e < A->rowPtr[r + 1]; ++e) ent.push_back({A->col[e], x, e - e_base, A->vals[e]});
         }
         o.nnz = static_cast<int64_t>(ent.size());
@@ -136,6 +161,7 @@ int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const st
         const uint32_t np = static_cast<uint32_t>((hot.size() + P - 1) / P);
         o.hot_cols = static_cast<int64_t>(hot.size());
         o.brow.assign(RB, kBkEmptyRow);
+        o.link.assign(RB, 0u);
         o.wstart.assign(kBkWaves, make_uint2(0u, 0u));
         if (np == 0) {
             o.hdr = make_uint4(0u, 0u, 0u, 0u);
@@ -147,9 +173,10 @@ int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const st
             const uint32_t c = hot[std::min(h, hot.size() - 1)].col;
             o.hcol[h] = (col_map ? static_cast<uint32_t>(col_map[c]) : c) * row_bytes32;
         }
-        // ---- the hot entries: (item, panel) -> records, at most run_max of them (the rest of such a run stays with the flat kernel)
-        std::vector<uint32_t> cnt_ip(static_cast<size_t>(n_it) * np, 0u);  // [item][panel]
-        std::vector<uint32_t> ent_panel(ent.size(), 0xFFFFFFFFu), ent_off(ent.size(), 0u);
+        // ---- the hot entries: (part, panel) -> records, at most run_max of them (the rest of such a run stays with the flat kernel);
+        // a row's hot nonzeros of one panel are dealt round-robin over its parts
+        std::vector<uint32_t> cnt_ip(static_cast<size_t>(n_sl) * np, 0u);  // [part][panel]
+        std::vector<uint32_t> ent_panel(ent.size(), 0xFFFFFFFFu), ent_off(ent.size(), 0u), ent_part(ent.size(), 0u);
         {
             std::vector<std::pair<uint32_t, uint32_t>> hot_by_col(hot.size());  // (col, index in panel order)
             for (size_t h = 0; h < hot.size(); ++h) hot_by_col[h] = {hot[h].col, static_cast<uint32_t>(h)};
@@ -166,34 +193,45 @@ int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const st
             }
             // in row order (ent is in (item, position in the row) order), so that WHICH entries of an over-long run stay hot is the
             // same whatever the sort above did with equal keys
+            std::vector<uint32_t> rr(np, 0u);
+            uint32_t cur_item = 0xFFFFFFFFu;
             for (size_t e = 0; e < ent.size(); ++e) {
+                if (ent[e].item != cur_item) {
+                    cur_item = ent[e].item;
+                    std::fill(rr.begin(), rr.end(), 0u);
+                }
                 if (ent_panel[e] == 0xFFFFFFFFu) continue;
-                uint32_t &c = cnt_ip[static_cast<size_t>(ent[e].item) * np + ent_panel[e]];
-                if (c >= run_max) ent_panel[e] = 0xFFFFFFFFu;
-                else ++c;
+                const uint32_t v = it[cur_item].v, part = first_slot[cur_item] + (rr[ent_panel[e]]++ % v);
+                uint32_t &c = cnt_ip[static_cast<size_t>(part) * np + ent_panel[e]];
+                if (c >= run_max) {
+                    ent_panel[e] = 0xFFFFFFFFu;
+                } else {
+                    ++c;
+                    ent_part[e] = part;
+                }
             }
         }
-        // ---- slots: rows with similar panel profiles side by side (a run is as long as the longest of its 4 slots): by the
-        // panel that holds most of the row's hot nonzeros, then by how many it has there, then by the total
-        std::vector<uint32_t> tot(n_it, 0u), top(n_it, 0u), top_cnt(n_it, 0u);
-        for (uint32_t x = 0; x < n_it; ++x)
+        // ---- slots: parts with similar panel profiles side by side (a run is as long as the longest of its 4 slots): by the
+        // panel that holds most of the part's hot nonzeros, then by how many it has there, then by the total
+        std::vector<uint32_t> tot(n_sl, 0u), top(n_sl, 0u), top_cnt(n_sl, 0u);
+        for (uint32_t x = 0; x < n_sl; ++x)
             for (uint32_t ph = 0; ph < np; ++ph) {
                 const uint32_t c = cnt_ip[static_cast<size_t>(x) * np + ph];
                 tot[x] += c;
                 if (c > top_cnt[x]) top_cnt[x] = c, top[x] = ph;
             }
-        std::vector<uint32_t> ord(n_it);
+        std::vector<uint32_t> ord(n_sl);
         std::iota(ord.begin(), ord.end(), 0u);
         std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t c) {
-            if ((tot[a] == 0) != (tot[c] == 0)) return tot[a] != 0;  // rows without a hot nonzero last: their slots stay empty
+            if ((tot[a] == 0) != (tot[c] == 0)) return tot[a] != 0;  // parts without a hot nonzero last: their slots stay empty
             if (top[a] != top[c]) return top[a] < top[c];
             if (top_cnt[a] != top_cnt[c]) return top_cnt[a] > top_cnt[c];
             return tot[a] > tot[c];
         });
-        std::vector<uint32_t> slot_of(n_it);
-        for (uint32_t s = 0; s < n_it; ++s) slot_of[ord[s]] = s;
+        std::vector<uint32_t> slot_of(n_sl);
+        for (uint32_t s = 0; s < n_sl; ++s) slot_of[ord[s]] = s;
         const uint32_t n_groups = rounds * kBkWaves;  // RB / 4
-        auto cnt_sp = [&](uint32_t s, uint32_t ph) -> uint32_t { return s < n_it ? cnt_ip[static_cast<size_t>(ord[s]) * np + ph] : 0u; };
+        auto cnt_sp = [&](uint32_t s, uint32_t ph) -> uint32_t { return s < n_sl ? cnt_ip[static_cast<size_t>(ord[s]) * np + ph] : 0u; };
         // records of every (slot, panel), in row order
         std::vector<uint32_t> beg_sp(static_cast<size_t>(RB) * np + 1, 0u);
         for (uint32_t s = 0; s < RB; ++s)
@@ -205,7 +243,7 @@ int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const st
                 if (ent_panel[e] == 0xFFFFFFFFu) continue;
                 uint32_t bits;
                 std::memcpy(&bits, &ent[e].val, 4);
-                rec_sp[fill[static_cast<size_t>(slot_of[ent[e].item]) * np + ent_panel[e]]++] = make_uint2(ent_off[e], bits);
+                rec_sp[fill[static_cast<size_t>(slot_of[ent_part[e]]) * np + ent_panel[e]]++] = make_uint2(ent_off[e], bits);
                 hot_mask[ent[e].e] = 1;
                 ++o.hot_nnz;
             }
@@ -231,20 +269,41 @@ int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const st
             w_load[best] += g_cost[g];
         }
         // ---- emit
+        // where every sorted slot ended up in the kernel's [round][wave][slot] numbering (the index of brow / link, and of the
+        // slot's 256 bytes of LDS when the parts of a row meet)
+        std::vector<uint32_t> place(RB, 0u);
+        for (uint32_t w = 0; w < kBkWaves; ++w)
+            for (uint32_t rd = 0; rd < rounds; ++rd) {
+                const uint32_t g = grp_of[static_cast<size_t>(w) * rounds + rd];
+                for (uint32_t s = 0; s < kBkSlots; ++s) place[g * kBkSlots + s] = (rd * kBkWaves + w) * kBkSlots + s;
+            }
+        // brow: the C row of an OWNER slot (part 0 of a row that has a hot nonzero anywhere), kBkEmptyRow for every other slot.
+        // link: owner of a multi-part row: kBkLinkOwner | place + 1 of its next part with a hot nonzero; such a part: kBkLinkPart |
+        // place + 1 of the next one (0 = the last).  Parts without a hot nonzero are left out of the chain.
+        o.link.assign(RB, 0u);
+        for (uint32_t x = 0; x < n_it; ++x) {
+            uint32_t any = 0;
+            for (uint32_t q = 0; q < it[x].v; ++q) any += tot[first_slot[x] + q];
+            if (any == 0) continue;
+            const uint32_t r = sched[it[x].spos];
+            const uint32_t own = place[slot_of[first_slot[x]]];
+            o.brow[own] = dst_map ? static_cast<uint32_t>(dst_map[r]) : r - static_cast<uint32_t>(r0);
+            uint32_t prev = own, n_chain = 0;
+            for (uint32_t q = 1; q < it[x].v; ++q) {
+                if (tot[first_slot[x] + q] == 0) continue;
+                const uint32_t pl = place[slot_of[first_slot[x] + q]];
+                o.link[prev] |= pl + 1;
+                o.link[pl] = kBkLinkPart;
+                prev = pl;
+                ++n_chain;
+            }
+            if (n_chain) o.link[own] |= kBkLinkOwner;
+        }
         const uint32_t cw = (np * rounds + 1) / 2;
         o.cnt.assign(static_cast<size_t>(kBkWaves) * cw, 0u);
         uint32_t step_pos = 0;
         for (uint32_t w = 0; w < kBkWaves; ++w) {
             const uint32_t w_first = step_pos;
-            for (uint32_t rd = 0; rd < rounds; ++rd) {  // brow[round][wave][slot]: only rows that have a hot nonzero are read and written back
-                const uint32_t g = grp_of[static_cast<size_t>(w) * rounds + rd];
-                for (uint32_t s = 0; s < kBkSlots; ++s) {
-                    const uint32_t sl = g * kBkSlots + s;
-                    if (sl >= n_it || tot[ord[sl]] == 0) continue;
-                    const uint32_t r = sched[it[ord[sl]]];
-                    o.brow[(static_cast<size_t>(rd) * kBkWaves + w) * kBkSlots + s] = dst_map ? static_cast<uint32_t>(dst_map[r]) : r - static_cast<uint32_t>(r0);
-                }
-            }
             for (uint32_t ph = 0; ph < np; ++ph)
                 for (uint32_t rd = 0; rd < rounds; ++rd) {
                     const uint32_t g = grp_of[static_cast<size_t>(w) * rounds + rd];
@@ -265,21 +324,24 @@ int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const st
                 }
             o.wstart[w] = make_uint2(w_first, step_pos - w_first);
         }
-        o.hdr = make_uint4(np, 0u, 0u, cw);
+        bool chains = false;
+        for (uint32_t l : o.link) chains = chains || l != 0;
+        o.multi = chains;
+        o.hdr = make_uint4(np | (chains ? 0x80000000u : 0u), 0u, 0u, cw);
     });
 
     // ---- concatenate (offsets are sequential; the copies run in parallel)
     std::vector<uint64_t> rec_at(static_cast<size_t>(nb) + 1, 0), cnt_at(static_cast<size_t>(nb) + 1, 0), hcol_at(static_cast<size_t>(nb) + 1, 0);
     for (int64_t b = 0; b < nb; ++b) {
         const BlockOut &o = out[static_cast<size_t>(b)];
-        if (o.hdr.w * 2 > kBkMaxCounts || o.hdr.x > max_panels) return FLEX_ERR_UNSUPPORTED;  // cannot happen: max_panels bounds both
+        if (o.hdr.w * 2 > kBkMaxCounts || (o.hdr.x & 0x7FFFFFFFu) > max_panels) return FLEX_ERR_UNSUPPORTED;  // cannot happen: max_panels bounds both
         rec_at[b + 1] = rec_at[b] + o.rec.size();
         cnt_at[b + 1] = cnt_at[b] + o.cnt.size();
         hcol_at[b + 1] = hcol_at[b] + o.hcol.size();
         img.nnz += o.nnz;
         img.hot_nnz += o.hot_nnz;
         img.hot_cols += o.hot_cols;
-        img.panels += o.hdr.x;
+        img.panels += o.hdr.x & 0x7FFFFFFFu;
         img.rows += o.rows;
     }
     if (rec_at[nb] / kBkSlots >= (uint64_t(1) << 32) || cnt_at[nb] >= (uint64_t(1) << 32) || hcol_at[nb] >= (uint64_t(1) << 32)) return FLEX_ERR_UNSUPPORTED;
@@ -287,6 +349,7 @@ int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const st
     img.hdr.resize(static_cast<size_t>(nb));
     img.wstart.resize(static_cast<size_t>(nb) * kBkWaves);
     img.brow.resize(static_cast<size_t>(nb) * RB);
+    img.link.resize(static_cast<size_t>(nb) * RB);
     img.cnt.resize(static_cast<size_t>(cnt_at[nb]));
     img.hcol.resize(static_cast<size_t>(hcol_at[nb]));
     img.rec.resize(static_cast<size_t>(rec_at[nb]));
@@ -296,6 +359,7 @@ int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const st
         const uint32_t step0 = static_cast<uint32_t>(rec_at[b] / kBkSlots);
         for (uint32_t w = 0; w < kBkWaves; ++w) img.wstart[static_cast<size_t>(b) * kBkWaves + w] = make_uint2(step0 + o.wstart[w].x, o.wstart[w].y);
         std::copy(o.brow.begin(), o.brow.end(), img.brow.begin() + static_cast<size_t>(b) * RB);
+        std::copy(o.link.begin(), o.link.end(), img.link.begin() + static_cast<size_t>(b) * RB);
         std::copy(o.cnt.begin(), o.cnt.end(), img.cnt.begin() + cnt_at[b]);
         std::copy(o.hcol.begin(), o.hcol.end(), img.hcol.begin() + hcol_at[b]);
         std::copy(o.rec.begin(), o.rec.end(), img.rec.begin() + rec_at[b]);

@@ -70,6 +70,7 @@ void free_plan_device(flex_plan *p) {
     (void)hipFree(p->d_bk_cnt);
     (void)hipFree(p->d_bk_hcol);
     (void)hipFree(p->d_bk_brow);
+    (void)hipFree(p->d_bk_link);
     (void)hipFree(p->d_bk_rec);
     if (p->done) (void)hipEventDestroy(p->done);
     p->done = nullptr;

@@ -49,7 +49,7 @@ struct flex_plan {
     // writes every row, the hot kernel adds to the rows of its blocks)
     uint4 *d_bk_hdr = nullptr;
     uint2 *d_bk_wstart = nullptr, *d_bk_rec = nullptr;
-    uint32_t *d_bk_cnt = nullptr, *d_bk_hcol = nullptr, *d_bk_brow = nullptr;
+    uint32_t *d_bk_cnt = nullptr, *d_bk_hcol = nullptr, *d_bk_brow = nullptr, *d_bk_link = nullptr;
     uint32_t bk_blocks = 0, bk_rounds = 0, bk_panel_rows = 0, bk_ablate = 0;
     int64_t bk_rows = 0, bk_nnz = 0, bk_hot_nnz = 0, bk_hot_cols = 0, bk_panels = 0, bk_records = 0;
     uint32_t n_tasks = 0, n_chunks = 0, n_slots = 0, n_split = 0, n_partials = 0;  // n_slots: chunk table incl. padding
@@ -109,7 +109,7 @@ inline PlanView plan_view(const flex_plan *p, bool fused, uint64_t *trace) {
                     p->xcd_remap ? 1u : 0u, p->lds_extra, p->rec_nt ? 1u : 0u, p->tile_group, trace};
 }
 inline BlockView block_view(const flex_plan *p) {
-    return BlockView{p->d_bk_hdr, p->d_bk_wstart, p->d_bk_cnt, p->d_bk_hcol, p->d_bk_brow, p->d_bk_rec, static_cast<uint64_t>(std::max<int64_t>(p->bk_records, 1)),
+    return BlockView{p->d_bk_hdr, p->d_bk_wstart, p->d_bk_cnt, p->d_bk_hcol, p->d_bk_brow, p->d_bk_link, p->d_bk_rec, static_cast<uint64_t>(std::max<int64_t>(p->bk_records, 1)),
                      p->bk_blocks, p->bk_rounds, p->bk_panel_rows, p->k, p->ldb, p->ldc, 1u, p->bk_ablate, p->trace};
 }
 inline TileView tile_view(const flex_plan *p) { return TileView{p->d_tile_a, p->d_tile_boff, p->d_tile_mask, p->d_rt_ptr, p->d_rt_rows, p->n_row_tiles}; }
@@ -143,12 +143,12 @@ int detect_dense_tiles(const flex_csr *A, int32_t r0, int32_t m, const std::vect
 
 // ---- hot blocks (block_plan.cpp)
 struct BlockKnobs {
-    uint32_t rounds = 8, panel_rows = kBkPanelMax, thr = 2, cap = 1024, max_panels = 31, min_last_panel = 32, run_max = kBkRunMax;
+    uint32_t rounds = 8, panel_rows = kBkPanelMax, thr = 2, cap = 256, max_panels = 31, min_last_panel = 32, run_max = kBkRunMax;
 };
 struct BlockImage {  // host copy of what BlockView points at
     std::vector<uint4> hdr;
     std::vector<uint2> wstart;
-    std::vector<uint32_t> cnt, hcol, brow;
+    std::vector<uint32_t> cnt, hcol, brow, link;
     RecordVec rec;
     uint32_t n_blocks = 0, rounds = 0, panel_rows = 0;
     int64_t rows = 0, nnz = 0, hot_nnz = 0, hot_cols = 0, panels = 0;

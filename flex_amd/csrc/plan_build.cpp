@@ -301,9 +301,9 @@ class PlanBuilder {
             kn.panel_rows = static_cast<uint32_t>(tn.block_panel_rows);
         }
         kn.thr = tn.block_thr ? static_cast<uint32_t>(tn.block_thr) : 2u;
-        // a row longer than this takes no slot (all of it stays flat, where long rows are cut into concurrent pieces): its hot
-        // nonzeros would be runs of one slot several times longer than its neighbours'
-        kn.cap = tn.block_cap ? static_cast<uint32_t>(std::min<int32_t>(tn.block_cap, 60000)) : static_cast<uint32_t>(std::clamp(6.0 * avg_deg, 64.0, 4096.0));
+        // nonzeros per slot: a longer row is spread over ceil(len / cap) slots, so that its runs are about as long as its neighbours'
+        // (a power-law graph keeps a third of its nonzeros in rows several times the average: they are the hottest ones)
+        kn.cap = tn.block_cap ? static_cast<uint32_t>(std::min<int32_t>(tn.block_cap, 60000)) : static_cast<uint32_t>(std::clamp(1.5 * avg_deg, 32.0, 4096.0));
         kn.min_last_panel = std::min<uint32_t>(32, kn.panel_rows / 4);
         BlockImage img;
         std::vector<uint8_t> hot_mask;
@@ -322,6 +322,7 @@ class PlanBuilder {
         if ((rc = upload(&p->d_bk_cnt, img.cnt, &p->device_bytes))) return rc;
         if ((rc = upload(&p->d_bk_hcol, img.hcol, &p->device_bytes))) return rc;
         if ((rc = upload(&p->d_bk_brow, img.brow, &p->device_bytes))) return rc;
+        if ((rc = upload(&p->d_bk_link, img.link, &p->device_bytes))) return rc;
         if ((rc = upload(&p->d_bk_rec, img.rec, &p->device_bytes))) return rc;
         p->bk_blocks = img.n_blocks;
         p->bk_rounds = img.rounds;

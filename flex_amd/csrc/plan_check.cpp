@@ -251,12 +251,13 @@ int flex_plan_self_check(const flex_plan *p) try {
         if ((rounds != 2 && rounds != 4 && rounds != 8) || P == 0 || P % 4 != 0 || P > kBkPanelMax || !p->off32) return FLEX_ERR_FORMAT;
         std::vector<uint4> hdr(nb);
         std::vector<uint2> wstart(static_cast<size_t>(nb) * kBkWaves), brec(static_cast<size_t>(p->bk_records));
-        std::vector<uint32_t> brow(static_cast<size_t>(nb) * RB);
+        std::vector<uint32_t> brow(static_cast<size_t>(nb) * RB), link(static_cast<size_t>(nb) * RB);
         if (cur != p->device) FLEX_HIP_TRY(hipSetDevice(p->device));
         bool ok_b = down(hdr.data(), p->d_bk_hdr, hdr.size() * sizeof(uint4)) && down(wstart.data(), p->d_bk_wstart, wstart.size() * sizeof(uint2)) &&
-                    down(brec.data(), p->d_bk_rec, brec.size() * sizeof(uint2)) && down(brow.data(), p->d_bk_brow, brow.size() * 4);
+                    down(brec.data(), p->d_bk_rec, brec.size() * sizeof(uint2)) && down(brow.data(), p->d_bk_brow, brow.size() * 4) &&
+                    down(link.data(), p->d_bk_link, link.size() * 4);
         uint64_t n_cnt = 0, n_hcol = 0;
-        for (const uint4 &h : hdr) n_cnt += static_cast<uint64_t>(h.w) * kBkWaves, n_hcol += static_cast<uint64_t>(h.x) * P;
+        for (const uint4 &h : hdr) n_cnt += static_cast<uint64_t>(h.w) * kBkWaves, n_hcol += static_cast<uint64_t>(h.x & 0x7FFFFFFFu) * P;
         std::vector<uint32_t> cnt(static_cast<size_t>(n_cnt)), hcol(static_cast<size_t>(n_hcol));
         ok_b = ok_b && down(cnt.data(), p->d_bk_cnt, cnt.size() * 4) && down(hcol.data(), p->d_bk_hcol, hcol.size() * 4);
         if (cur != p->device) (void)hipSetDevice(cur);
@@ -267,9 +268,11 @@ int flex_plan_self_check(const flex_plan *p) try {
         int64_t panels = 0, real = 0;
         std::vector<uint8_t> added(static_cast<size_t>(p->c_rows), 0);
         for (uint32_t b = 0; b < nb; ++b) {
-            const uint4 h = hdr[b];
+            uint4 h = hdr[b];
+            const bool chains = (h.x >> 31) != 0;
+            h.x &= 0x7FFFFFFFu;
             if (h.x == 0) {
-                if (h.w != 0) return FLEX_ERR_FORMAT;
+                if (h.w != 0 || chains) return FLEX_ERR_FORMAT;
             } else if (h.y != at_hcol || h.z != at_cnt || h.w != (h.x * rounds + 1) / 2 || h.x * rounds + rounds > kBkMaxCounts || h.y % 4 != 0) {
                 return FLEX_ERR_FORMAT;
             }
@@ -300,11 +303,29 @@ int flex_plan_self_check(const flex_plan *p) try {
                 if (steps != ws.y) return FLEX_ERR_FORMAT;
                 at_step += steps;
             }
+            // slots: an owner names a C row the flat plan writes, once over all blocks; the chain of a multi-part row starts at its
+            // owner, runs through slots that are marked as parts and hold no row, and every such part is on exactly one chain
+            std::vector<uint8_t> on_chain(RB, 0);
+            bool any_link = false;
             for (uint32_t s = 0; s < RB; ++s) {
-                const uint32_t row = brow[static_cast<size_t>(b) * RB + s];
+                const uint32_t row = brow[static_cast<size_t>(b) * RB + s], l = link[static_cast<size_t>(b) * RB + s];
+                any_link = any_link || l != 0;
+                if (l & ~(kBkLinkOwner | kBkLinkPart | 0xFFFFu)) return FLEX_ERR_FORMAT;
+                if ((l & kBkLinkOwner) && ((l & kBkLinkPart) || (l & 0xFFFFu) == 0 || row == kBkEmptyRow)) return FLEX_ERR_FORMAT;
+                if ((l & kBkLinkPart) && row != kBkEmptyRow) return FLEX_ERR_FORMAT;
+                if (!(l & (kBkLinkOwner | kBkLinkPart)) && l != 0) return FLEX_ERR_FORMAT;
                 if (row == kBkEmptyRow) continue;
                 if (row >= p->c_rows || !written[row] || added[row]++) return FLEX_ERR_FORMAT;
+                if (l & kBkLinkOwner) {
+                    uint32_t hops = 0;
+                    for (uint32_t n = l & 0xFFFFu; n != 0; n = link[static_cast<size_t>(b) * RB + n - 1] & 0xFFFFu) {
+                        if (n > RB || ++hops > RB || !(link[static_cast<size_t>(b) * RB + n - 1] & kBkLinkPart) || on_chain[n - 1]++) return FLEX_ERR_FORMAT;
+                    }
+                }
             }
+            for (uint32_t s = 0; s < RB; ++s)
+                if (((link[static_cast<size_t>(b) * RB + s] & kBkLinkPart) != 0) != (on_chain[s] == 1)) return FLEX_ERR_FORMAT;
+            if (any_link != chains) return FLEX_ERR_FORMAT;
         }
         if (at_step * kBkSlots != brec.size() || at_hcol != hcol.size() || at_cnt != cnt.size() || panels != p->bk_panels || real != p->bk_hot_nnz) return FLEX_ERR_FORMAT;
     }

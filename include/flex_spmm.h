@@ -155,7 +155,7 @@ typedef struct flex_plan_tuning {
     int32_t block_rounds;     /* rows per slot: 2, 4 or 8; a block is rounds x 60 rows (8; 4 / 2 while there are few blocks per CU) */
     int32_t block_panel_rows; /* B rows per LDS panel: a multiple of 4, at most 304 (304) */
     int32_t block_thr;        /* a column is hot (staged) when at least this many nonzeros of the block use it (2) */
-    int32_t block_cap;        /* rows longer than this take no slot: all of their nonzeros stay with the flat kernel (6 x the average degree) */
+    int32_t block_cap;        /* nonzeros per slot: a longer row is spread over ceil(len / cap) slots, summed through LDS (1.5 x the average degree) */
     int32_t block_ablate;     /* timing-only experiments, the RESULT IS WRONG: 1 no panel staging, 2 no panel work */
     int32_t tile_group;       /* multi-tile launches: workgroups per group -- every XCD's slice of the schedule is walked group by group, all
                                  column tiles of a group back to back, so that a group's records are re-read from the Infinity Cache rather
@@ -217,7 +217,7 @@ typedef struct flex_plan_info {
     int64_t n_records;    /* (col,val) records the vector kernel streams per column tile: nnz - tile_nnz + padding */
     /* the hot-block path (0 everywhere when the plan has no blocks) */
     int64_t n_blocks;         /* blocks: one workgroup each (per 64-column tile) */
-    int64_t block_rows;       /* rows that hold a slot in a block (empty and very long rows hold none) */
+    int64_t block_rows;       /* rows that hold slots in a block (empty rows, and rows longer than a whole block of slots, hold none) */
     int64_t block_nnz;        /* nonzeros of those rows */
     int64_t block_hot_nnz;    /* nonzeros in the block image: they read their B row from an LDS panel and are NOT in the flat plan's records */
     int64_t block_hot_cols;   /* B rows staged, summed over blocks: block_hot_nnz / block_hot_cols = u, the reuse of a staged row */

@@ -155,7 +155,7 @@ def test_hot_blocks_in_a_hip_graph_and_on_two_streams():
     k = 128
     Bg, Ba = random_B(g.n, k, 1), random_B(a.n, k, 2)
     pg = Plan(g, k, order=flex_amd.FLEX_ORDER_CLUSTER, tuning=BLOCKS)
-    pa = Plan(a, k, tuning=dict(BLOCKS, block_cap=30))
+    pa = Plan(a, k, tuning=dict(BLOCKS, block_cap=30))  # rows beyond 30 nonzeros are spread over several slots
     assert pg.info()["n_blocks"] > 0 and pa.info()["n_blocks"] > 0 and pa.info()["n_split_rows"] > 0
     dg, da = dev(Bg), dev(Ba)
     Cg = torch.zeros((g.m, k), device="cuda")

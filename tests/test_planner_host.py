@@ -234,7 +234,7 @@ def test_descriptor_without_the_range_flag_refuses_a_range(sim):
 @pytest.mark.parametrize("rounds,panel_rows,thr,cap", [(8, 304, 2, 0), (2, 64, 2, 40), (4, 128, 3, 24), (8, 300, 4, 0), (4, 8, 2, 16)])
 def test_hot_block_plans_are_partitions(sim, rounds, panel_rows, thr, cap):
     """The hot-block route (the matrix is split: nonzeros with reuse inside a block of rounds x 60 rows go to LDS-staged B panels,
-    the rest -- and every row longer than `cap` -- stays with the flat planner): the device image must be a partition of the work
+    the rest stays with the flat planner; a row longer than `cap` is spread over several slots): the device image must be a partition of the work
     (flex_plan_self_check reads the block tables and every record stream back; flat records + hot records = every nonzero) for
     every shape of the knobs."""
     a = random_csr(9000, 9000, 20, seed=31, long_rows={5: 8000, 77: 1200, 4000: 300, 8999: 150}, empty_frac=0.05)
@@ -253,8 +253,11 @@ def test_hot_block_plans_are_partitions(sim, rounds, panel_rows, thr, cap):
         assert i["n_tasks"] >= mat.m  # ... and still every row: the flat kernel writes all of C, the hot kernel adds to it
         if mat is g and order == flex_amd.FLEX_ORDER_CLUSTER and rounds >= 4 and thr == 2 and panel_rows >= 64:
             assert i["block_hot_nnz"] > 0.3 * mat.nnz  # the planted communities are found as hot columns
-    # a row longer than the cap holds no slot: with a tiny cap nothing is left for the blocks
-    assert flex_amd.Plan(g, 128, order=flex_amd.FLEX_ORDER_CLUSTER, tuning=dict(knobs, block_cap=1)).info()["block_hot_nnz"] == 0
+    # a row longer than the cap is spread over several slots (parts chained through LDS); with a tiny cap every row is, and rows
+    # longer than a whole block of slots hold none
+    for tiny in (1, 3):
+        pt = flex_amd.Plan(g, 128, order=flex_amd.FLEX_ORDER_CLUSTER, tuning=dict(knobs, block_cap=tiny))
+        pt.self_check()
     # shards and mapped plans go through the route too
     vo, gp = flex_amd.perm_csr(g, flex_amd.order_cluster(g))
     flex_amd.Plan(gp, 128, vo_mp=vo, tuning=knobs).self_check()

@@ -17,7 +17,7 @@ if os.environ.get("PROBE_LIB"):  # an experiment build of the library (make -C f
 from tools._timing import timeit  # noqa: E402
 
 args = sys.argv[1:] or ["reddit", "128"]
-grid = os.environ.get("BLOCK_SWEEP", "8:304:2:0,8:304:3:0,4:304:2:0,8:304:2:0:2,8:304:2:0:3")  # a 5th field = block_ablate (timing only)
+grid = os.environ.get("BLOCK_SWEEP", "8:304:2:0,8:304:3:0,4:304:2:0,8:304:2:0:2,8:304:2:0:3,8:304:2:120,8:304:2:400")  # a 5th field = block_ablate (timing only)
 for name, k in zip(args[0::2], (int(x) for x in args[1::2])):
     gen = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in os.environ.get("GEN", "").split(",") if kv}  # e.g. GEN=p_in=0.75,p_near=0.25
     if gen:
