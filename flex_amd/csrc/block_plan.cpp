@@ -44,6 +44,7 @@ struct BlockOut {
     std::vector<uint32_t> cnt, hcol, brow, link;
     std::vector<uint2> rec;
     int64_t hot_nnz = 0, nnz = 0, hot_cols = 0, rows = 0;
+    int64_t cand_nnz = 0, lost_panels = 0, lost_last = 0, lost_run = 0;  // FLEX_PLAN_TIMING: where candidates (column uses >= thr) were left cold
     bool multi = false;  // some row of the block has several parts
 };
 
@@ -147,14 +148,17 @@ int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const st
             if (z1 - z >= kn.thr) hot.push_back({c, static_cast<uint32_t>(z1 - z), colpos.empty() ? c : colpos[c]});
             z = z1;
         }
+        for (const Hot &h : hot) o.cand_nnz += h.uses;
         if (hot.size() > static_cast<size_t>(max_panels) * P) {  // more than fits the run counts: the most used ones
             std::nth_element(hot.begin(), hot.begin() + static_cast<size_t>(max_panels) * P, hot.end(),
                              [](const Hot &a, const Hot &c) { return a.uses != c.uses ? a.uses > c.uses : a.col < c.col; });
+            for (size_t h = static_cast<size_t>(max_panels) * P; h < hot.size(); ++h) o.lost_panels += hot[h].uses;
             hot.resize(static_cast<size_t>(max_panels) * P);
         }
         // a last panel that would hold only a few rows costs a barrier and a DMA round for little: those columns stay with the flat kernel
         if (hot.size() % P != 0 && hot.size() % P < kn.min_last_panel) {
             std::sort(hot.begin(), hot.end(), [](const Hot &a, const Hot &c) { return a.uses != c.uses ? a.uses > c.uses : a.col < c.col; });
+            for (size_t h = hot.size() / P * P; h < hot.size(); ++h) o.lost_last += hot[h].uses;
             hot.resize(hot.size() / P * P);
         }
         std::sort(hot.begin(), hot.end(), [](const Hot &a, const Hot &c) { return a.pos != c.pos ? a.pos < c.pos : a.col < c.col; });
@@ -205,6 +209,7 @@ int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const st
                 uint32_t &c = cnt_ip[static_cast<size_t>(part) * np + ent_panel[e]];
                 if (c >= run_max) {
                     ent_panel[e] = 0xFFFFFFFFu;
+                    ++o.lost_run;
                 } else {
                     ++c;
                     ent_part[e] = part;
@@ -343,6 +348,10 @@ int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const st
         img.hot_cols += o.hot_cols;
         img.panels += o.hdr.x & 0x7FFFFFFFu;
         img.rows += o.rows;
+        img.cand_nnz += o.cand_nnz;
+        img.lost_panels += o.lost_panels;
+        img.lost_last += o.lost_last;
+        img.lost_run += o.lost_run;
     }
     if (rec_at[nb] / kBkSlots >= (uint64_t(1) << 32) || cnt_at[nb] >= (uint64_t(1) << 32) || hcol_at[nb] >= (uint64_t(1) << 32)) return FLEX_ERR_UNSUPPORTED;
     img.n_blocks = static_cast<uint32_t>(nb);

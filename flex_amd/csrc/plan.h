@@ -152,6 +152,7 @@ struct BlockImage {  // host copy of what BlockView points at
     RecordVec rec;
     uint32_t n_blocks = 0, rounds = 0, panel_rows = 0;
     int64_t rows = 0, nnz = 0, hot_nnz = 0, hot_cols = 0, panels = 0;
+    int64_t cand_nnz = 0, lost_panels = 0, lost_last = 0, lost_run = 0;  // candidates (column uses >= thr) and where some were left cold
 };
 // What share of the nonzeros of rows sched[...] would be HOT (their column used by >= thr nonzeros of the same block of `rows`
 // schedule-consecutive rows), looked at in every `stride`-th block: the planner's cheap look before it commits to the block route.

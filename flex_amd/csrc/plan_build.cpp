@@ -300,7 +300,7 @@ class PlanBuilder {
             if (tn.block_panel_rows % 4 != 0 || tn.block_panel_rows > static_cast<int32_t>(kBkPanelMax)) return FLEX_ERR_INVALID;
             kn.panel_rows = static_cast<uint32_t>(tn.block_panel_rows);
         }
-        kn.thr = tn.block_thr ? static_cast<uint32_t>(tn.block_thr) : 2u;
+        kn.thr = tn.block_thr ? static_cast<uint32_t>(tn.block_thr) : 3u;  // measured: 3 is 1 % ahead of 2 where the route pays (fewer panels, less staging)
         // nonzeros per slot: a longer row is spread over ceil(len / cap) slots, so that its runs are about as long as its neighbours'
         // (a power-law graph keeps a third of its nonzeros in rows several times the average: they are the hottest ones)
         kn.cap = tn.block_cap ? static_cast<uint32_t>(std::min<int32_t>(tn.block_cap, 60000)) : static_cast<uint32_t>(std::clamp(1.5 * avg_deg, 32.0, 4096.0));
@@ -316,6 +316,13 @@ class PlanBuilder {
         u.block_panel_rows = static_cast<int32_t>(kn.panel_rows);
         u.block_thr = static_cast<int32_t>(kn.thr);
         u.block_cap = static_cast<int32_t>(kn.cap);
+        if (timing)
+            std::fprintf(stderr, "plan: hot blocks %u x %u slots, %lld rows, %lld nnz; candidates %.1f %%, hot %.1f %% (left cold: panel budget %.1f %%, short last panel %.1f %%, runs beyond %u steps %.1f %%), "
+                         "u %.2f, records / hot %.2f, panels / block %.1f\n", img.n_blocks, kn.rounds * kBkRowsPerRound, static_cast<long long>(img.rows), static_cast<long long>(img.nnz),
+                         100.0 * img.cand_nnz / std::max<int64_t>(img.nnz, 1), 100.0 * img.hot_nnz / std::max<int64_t>(img.nnz, 1), 100.0 * img.lost_panels / std::max<int64_t>(img.nnz, 1),
+                         100.0 * img.lost_last / std::max<int64_t>(img.nnz, 1), kn.run_max, 100.0 * img.lost_run / std::max<int64_t>(img.nnz, 1),
+                         static_cast<double>(img.hot_nnz) / std::max<int64_t>(img.hot_cols, 1), static_cast<double>(img.rec.size()) / std::max<int64_t>(img.hot_nnz, 1),
+                         static_cast<double>(img.panels) / std::max<uint32_t>(img.n_blocks, 1));
         if (img.hot_nnz == 0) return FLEX_OK;  // nothing has reuse: a flat plan
         if ((rc = upload(&p->d_bk_hdr, img.hdr, &p->device_bytes))) return rc;
         if ((rc = upload(&p->d_bk_wstart, img.wstart, &p->device_bytes))) return rc;
@@ -336,6 +343,10 @@ class PlanBuilder {
         p->bk_ablate = static_cast<uint32_t>(tn.block_ablate);
         img = BlockImage{};
         keep_unmarked(hot_mask, 0);
+        // what stays flat is a different matrix -- by construction the nonzeros WITHOUT reuse nearby: its tile width and chunk budget
+        // follow ITS degree (the Amazon shape's 40 % that stay cold: degree 69, so 64-column tiles and two passes over the records
+        // instead of 32-column tiles and four)
+        choose_tile_width();
         return FLEX_OK;
     }
 
@@ -809,11 +820,14 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
     const bool can_block = block_shapes && force_G == 0 && r1 > r0 && tuning.mfma != 1 && tuning.two_d != 1 && tuning.blocks != 2;
     bool want_blocks = tuning.blocks == 1 && can_block;
     std::vector<uint32_t> local_cache;
-    // The rule (tuning.blocks = 0): the split pays where a sizeable share of the nonzeros has reuse inside a block of a few hundred
-    // schedule-consecutive rows AND the launch is long enough for a second kernel's start-up and tail to disappear in it.  The look
-    // costs one sort of every 16th block's columns; the schedule it needs is computed once and handed on.
+    // The rule (tuning.blocks = 0), from what was measured on MI355X.  What stays flat after the split is, record for
+    // record, an L2 miss (its launch time is cold nonzeros x 4k bytes at the fabric's ~7.3 TB/s), and the flat kernel ALONE already
+    // serves the hot nonzeros out of its L2s underneath its own misses: the split pays only where the cold share is small and the
+    // launch long enough for a second kernel -- the Amazon shape without uniformly random edges (29 % cold) 7.62 -> 6.51 ms; its
+    // preset (39 % cold) 8.25 -> 9.5, the Reddit shapes (a tenth of the rows) 0.76-0.97x.  The look costs one sort of every 16th
+    // block's columns; the schedule it needs is computed once and handed on.
     const int64_t nnz_in = static_cast<int64_t>(A->rowPtr[r1]) - A->rowPtr[r0];
-    if (tuning.blocks == 0 && can_block && static_cast<int64_t>(r1 - r0) >= 120000 && nnz_in >= 32ll * (r1 - r0)) {
+    if (tuning.blocks == 0 && can_block && static_cast<int64_t>(r1 - r0) >= 480 * 2048 && nnz_in >= 48ll * (r1 - r0)) {
         if (!sched_cache) sched_cache = &local_cache;
         std::vector<uint32_t> *sched = nullptr, *colpos = nullptr;
         int rc;
@@ -821,9 +835,9 @@ int build_plan(flex_plan *p, const flex_csr *A, int32_t r0, int32_t r1, const in
             PlanBuilder pre(p, A, r0, r1, col_map, dst_map, flags, tuning, sched_cache, 0);
             if ((rc = pre.schedule_only(&sched, &colpos))) return rc;
         }
-        const double share = estimate_hot_share(A, *sched_cache, 480, 2, 16);
-        if (plan_timing_enabled()) std::fprintf(stderr, "plan: hot share of 480-row blocks (thr 2, every 16th) %.3f\n", share);
-        want_blocks = share >= 0.5;
+        const double share = estimate_hot_share(A, *sched_cache, 480, 3, 16);
+        if (plan_timing_enabled()) std::fprintf(stderr, "plan: hot share of 480-row blocks (thr 3, every 16th) %.3f\n", share);
+        want_blocks = share >= 0.72;
     }
     return PlanBuilder(p, A, r0, r1, col_map, dst_map, flags, tuning, sched_cache, force_G, want_blocks).run();
 } catch (const std::bad_alloc &) {  // any host allocation of any stage

@@ -149,12 +149,12 @@ typedef struct flex_plan_tuning {
     flex_cluster_tuning cluster;
     /* the hot-block path (the matrix is SPLIT: nonzeros with reuse inside a block of rows are multiplied out of LDS-staged B panels by
        their own kernel after the flat kernel has done the rest) */
-    int32_t blocks;           /* 1: split, 2: never (rule: k >= 64, >= 120 000 rows of average degree >= 32, and a sampled look finds
-                                 >= 50 % of the nonzeros in columns that a block of 480 rows uses twice or more; needs 16-byte aligned
-                                 operands: flex_spmm returns FLEX_ERR_UNSUPPORTED for others) */
+    int32_t blocks;           /* 1: split, 2: never (rule: k >= 64 and a very large input -- >= 983 040 rows of average degree >= 48 -- on which
+                                 a sampled look finds >= 72 % of the nonzeros in columns that a block of 480 rows uses three times or more;
+                                 needs 16-byte aligned operands: flex_spmm returns FLEX_ERR_UNSUPPORTED for others) */
     int32_t block_rounds;     /* rows per slot: 2, 4 or 8; a block is rounds x 60 rows (8; 4 / 2 while there are few blocks per CU) */
     int32_t block_panel_rows; /* B rows per LDS panel: a multiple of 4, at most 304 (304) */
-    int32_t block_thr;        /* a column is hot (staged) when at least this many nonzeros of the block use it (2) */
+    int32_t block_thr;        /* a column is hot (staged) when at least this many nonzeros of the block use it (3) */
     int32_t block_cap;        /* nonzeros per slot: a longer row is spread over ceil(len / cap) slots, summed through LDS (1.5 x the average degree) */
     int32_t block_ablate;     /* timing-only experiments, the RESULT IS WRONG: 1 no panel staging, 2 no panel work */
     int32_t tile_group;       /* multi-tile launches: workgroups per group -- every XCD's slice of the schedule is walked group by group, all
