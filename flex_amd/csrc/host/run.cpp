@@ -289,10 +289,13 @@ void run(DataLoader &input_vo) {
                     r.sched.c_str(), r.t_us, r.gflops, r.balg_gbs, r.balg_gbs / 8000.0 * 100,
                     static_cast<long long>(r.info.n_chunks), static_cast<long long>(r.info.n_split_rows),
                     r.stats.reuse_wave, r.stats.reuse_xcd, r.imb.cu_busy_imb_pct, r.plan_ms, r.plan_ms * 1e3 / r.t_us, r.errs);
-        if (r.hbm_bytes >= 0)  // ≙ the reference's DRAM GB/s, %Pk and measured u per table row (flex.cu:5237)
-            std::printf("     counters: HBM-side %.1f MB/launch = %.2fx Balg, %.0f GB/s (%.1f %% of 8 TB/s), L2 hit %.3f, u %.2f\n",
+        if (r.hbm_bytes >= 0) {  // ≙ the reference's DRAM GB/s, %Pk and measured u per table row (flex.cu:5237)
+            char u_txt[32] = "n/a (B stayed in the L2s)";  // nothing was fetched beyond A: there is no reuse to divide by
+            if (r.u_meas >= 0) std::snprintf(u_txt, sizeof u_txt, "%.2f", r.u_meas);
+            std::printf("     counters: HBM-side %.1f MB/launch = %.2fx Balg, %.0f GB/s (%.1f %% of 8 TB/s), L2 hit %.3f, u %s\n",
                         r.hbm_bytes * 1e-6, r.hbm_bytes / (r.balg_gbs * r.t_us * 1e3), r.hbm_bytes / r.t_us * 1e-3,
-                        r.hbm_bytes / r.t_us * 1e-3 / 8000.0 * 100, r.l2_hit, r.u_meas);
+                        r.hbm_bytes / r.t_us * 1e-3 / 8000.0 * 100, r.l2_hit, u_txt);
+        }
         if (r.l2_bytes >= 0)  // ≙ the L1<->L2 bytes and "Per Mult / Num Insns" columns (flex.cu:5279-5330, 5350-5420)
             std::printf("               L1<->L2 %.1f MB/launch (%.0f GB/s), u at L1 %.2f; wave insns per 64 FMAs: vmem_rd %.2f valu %.2f lds %.2f salu %.2f\n",
                         r.l2_bytes * 1e-6, r.l2_bytes / r.t_us * 1e-3, r.u_l1, r.vmem_rd, r.valu, r.lds, r.salu);

@@ -172,10 +172,16 @@ class PlanBuilder {
         avg_deg = m > 0 ? static_cast<double>(A->rowPtr[r1] - A->rowPtr[r0]) / m : 0.0;
         G = 8;
         while (4 * G < k && G < 64) G <<= 1;
+        // k <= 16: a B row is at most 64 bytes, and four lanes cover it -- 16 records per step instead of 8 with half of the lanes
+        // gathering a column nobody stores (≙ the reference's narrow kernel, flex.cu:81-118: one thread per (row, column), 128 / k rows
+        // per block).  Rows are padded to whole steps, so the narrow tile is the rule only where rows are long enough to fill them.
+        const bool narrow_ok = k <= 16 && k % 4 == 0;
         if (force_G) {
             G = std::min(G, force_G);
-        } else if (const int g_t = tn.lanes_per_nz; g_t == 8 || g_t == 16 || g_t == 32 || g_t == 64) {
-            G = std::min<int>(G, g_t);  // tuning experiments
+        } else if (const int g_t = tn.lanes_per_nz; g_t == 8 || g_t == 16 || g_t == 32 || g_t == 64 || (g_t == 4 && narrow_ok)) {
+            G = g_t == 4 ? 4 : std::min<int>(G, g_t);  // tuning experiments
+        } else if (narrow_ok && avg_deg >= 8.0) {
+            G = 4;
         } else {
             G = std::min(G, 32);  // k = 256 as two 128-column tiles beats one 256-column tile on every shape measured
             if (avg_deg >= 24.0) G = std::min(G, 16);

@@ -79,6 +79,19 @@ __device__ __forceinline__ float pair8(float a, float b) {
     return r;
 }
 
+// pair4 (a,b): lanes with bit 2 clear get a[l]+a[l^4], the others b[l]+b[l^4].  l^4 swaps quads 0<->1 and 2<->3 of a 16-lane row:
+// quads 0 and 2 (bank_mask 0x5) take their partner from the quad ABOVE (row_ror:12 = rotate left by 4), quads 1 and 3
+// (bank_mask 0xa) from the quad below (row_ror:4).
+__device__ __forceinline__ float pair4(float a, float b) {
+    float r;
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xa"
+        : "=&v"(r)
+        : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ float pair16(float a, float b) {
     // v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its second:
     // (a,b) -> {a0,b0,a2,b2}, {a1,b1,a3,b3}; their sum is a0+a1 on row 0, b0+b1 on row 1, ...
@@ -102,21 +115,23 @@ __device__ __forceinline__ float pair32(float a, float b) {
 //   G=32: 4 values at c0, lanes of slot 0     (all-reduce over 2 slots)
 //   G=16: 4 values at c0, lanes of slot 0     (all-reduce over 4 slots)
 //   G=8 : 1 value  at c0 + 2*bit3 + bit4, lower wave half  (pair8 twice, pair16, then both halves summed)
+//   G=4 : 1 value  at c0 + 2*bit2 + bit3, lanes 0-15       (pair4 twice, pair8, then the four 16-lane rows summed)   [k <= 16]
 template <int G>
 struct RowOut {
-    static constexpr int kVals = G == 8 ? 1 : 4;
+    static constexpr int kVals = G <= 8 ? 1 : 4;
     float v[kVals];
 };
 
 template <int G>
 __device__ __forceinline__ int row_out_col(int lane, int c0) {
     if constexpr (G == 8) return c0 + 2 * ((lane >> 3) & 1) + ((lane >> 4) & 1);
+    else if constexpr (G == 4) return c0 + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
     else return c0;
 }
 
 template <int G>
 __device__ __forceinline__ bool row_out_lane(int lane) {  // does this lane store
-    return G == 8 ? lane < 32 : lane < G;
+    return G == 8 ? lane < 32 : G == 4 ? lane < 16 : lane < G;
 }
 
 template <int G>
@@ -125,6 +140,10 @@ __device__ __forceinline__ RowOut<G> reduce_row(const float4 &acc) {
     if constexpr (G == 8) {
         const float t = pair16(pair8(acc.x, acc.z), pair8(acc.y, acc.w));
         o.v[0] = pair32(t, t);  // both halves hold the same columns: plain sum, the lower half stores
+    } else if constexpr (G == 4) {
+        const float t = pair8(pair4(acc.x, acc.z), pair4(acc.y, acc.w));
+        const float h = pair16(t, t);  // the four 16-lane rows hold the same columns: plain sums, the first row stores
+        o.v[0] = pair32(h, h);
     } else {
         float4 r = acc;
         if constexpr (G <= 16) {
@@ -162,6 +181,16 @@ __device__ __forceinline__ void store_row_out(float *ptr, const RowOut<G> &o) {
 template <int G>
 __device__ __forceinline__ float4 reduce_full(const float4 &acc) {
     float4 r = acc;
+    if constexpr (G <= 4) {  // lane ^ 4: quads 0 and 2 read the quad above (row_ror:12), quads 1 and 3 the quad below (row_ror:4)
+        auto partner = [](float x) {
+            const int lo = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x12C, 0xf, 0x5, false);
+            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(lo, __builtin_bit_cast(int, x), 0x124, 0xf, 0xa, false));
+        };
+        r.x += partner(r.x);
+        r.y += partner(r.y);
+        r.z += partner(r.z);
+        r.w += partner(r.w);
+    }
     if constexpr (G <= 8) {  // lane ^ 8 inside each 16-lane row: row_ror:8
         r.x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r.x), 0x128, 0xf, 0xf, false));
         r.y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, r.y), 0x128, 0xf, 0xf, false));
@@ -710,6 +739,7 @@ int launch_spmm(const PlanView &v, int lanes_per_nz, bool off32, bool vec4, cons
         }
     }
     switch (lanes_per_nz) {  // U: 4 KiB in flight per wave on the narrow tiles, 8 KiB on the wide ones (U=8 on G<=16 measured the same)
+        case 4: return launch_v4_off<4, 4>(v, off32, dB, dC, s);
         case 8: return launch_v4_off<8, 4>(v, off32, dB, dC, s);
         case 16: return launch_v4_off<16, 4>(v, off32, dB, dC, s);
         case 32: return launch_v4_off<32, 8>(v, off32, dB, dC, s);
@@ -722,6 +752,7 @@ int launch_spmm(const PlanView &v, int lanes_per_nz, bool off32, bool vec4, cons
 int launch_spmm_stamped(const PlanView &v, int lanes_per_nz, bool off32, const float *dB, float *dC, hipStream_t s) {
     if (v.n_chunks == 0) return FLEX_OK;
     switch (lanes_per_nz) {
+        case 4: return launch_stamped<4, 4>(v, off32, dB, dC, s);
         case 8: return launch_stamped<8, 4>(v, off32, dB, dC, s);
         case 16: return launch_stamped<16, 4>(v, off32, dB, dC, s);
         case 32: return launch_stamped<32, 8>(v, off32, dB, dC, s);
@@ -737,6 +768,7 @@ int kernel_attributes(int lanes_per_nz, bool off32, bool vec4, hipFuncAttributes
         fn = off32 ? reinterpret_cast<const void *>(spmm_generic_kernel<true>) : reinterpret_cast<const void *>(spmm_generic_kernel<false>);
     } else {
         switch (lanes_per_nz) {
+            case 4: fn = off32 ? reinterpret_cast<const void *>(spmm_flat_kernel<4, true, 4, kWavesPerBlock>) : reinterpret_cast<const void *>(spmm_flat_kernel<4, false, 4, kWavesPerBlock>); break;
             case 8: fn = off32 ? reinterpret_cast<const void *>(spmm_flat_kernel<8, true, 4, kWavesPerBlock>) : reinterpret_cast<const void *>(spmm_flat_kernel<8, false, 4, kWavesPerBlock>); break;
             case 16: fn = off32 ? reinterpret_cast<const void *>(spmm_flat_kernel<16, true, 4, kWavesPerBlock>) : reinterpret_cast<const void *>(spmm_flat_kernel<16, false, 4, kWavesPerBlock>); break;
             case 32: fn = off32 ? reinterpret_cast<const void *>(spmm_flat_kernel<32, true, 8, kWavesPerBlock>) : reinterpret_cast<const void *>(spmm_flat_kernel<32, false, 8, kWavesPerBlock>); break;

@@ -697,6 +697,39 @@ def test_two_plans_on_two_streams_concurrently():
     assert np.array_equal(c1.cpu().numpy(), ref1) and np.array_equal(c2.cpu().numpy(), ref2)
 
 
+@pytest.mark.parametrize("k", [4, 8, 12, 16])
+@pytest.mark.parametrize("split_rows", [1, 2])
+def test_narrow_tile_for_k_up_to_16(knobs, k, split_rows):
+    """k <= 16 (≙ the reference's narrow kernel, flex.cu:81-118): four lanes per record, sixteen records per step.  By rule from
+    an average degree of 8; forced on a low-degree graph; against the oracle, against the 8-lane tile of the same plan shape, with
+    rows cut into pieces under both forms of the split-row sum."""
+    knobs.set(split_rows=split_rows)
+    a = random_csr(6000, 6000, 14, seed=101, long_rows={7: 5000, 300: 900, 4000: 70})
+    B = random_B(a.n, k, 9)
+    for order in (FLEX_ORDER_NATURAL, flex_amd.FLEX_ORDER_CLUSTER):
+        p = Plan(a, k, order=order)
+        assert p.info()["lanes_per_nz"] == 4 and p.info()["n_split_rows"] >= 2
+        p.self_check()
+        C4 = run_plan(p, B)
+        assert_matches_oracle(a, B, C4)
+        assert np.array_equal(C4, run_plan(p, B))
+        knobs.set(lanes_per_nz=8)
+        p8 = Plan(a, k, order=order)
+        assert p8.info()["lanes_per_nz"] == 8
+        assert oracle.rescheck(run_plan(p8, B), C4, a.rowPtr)[0] == 0
+        knobs.clear("lanes_per_nz")
+    low = random_csr(5000, 5000, 3, seed=102)  # average degree 3: the rule keeps the 8-lane tile, the knob forces the narrow one
+    Bl = random_B(low.n, k, 10)
+    assert Plan(low, k).info()["lanes_per_nz"] == 8
+    knobs.set(lanes_per_nz=4)
+    pl = Plan(low, k)
+    assert pl.info()["lanes_per_nz"] == 4
+    pl.self_check()
+    assert_matches_oracle(low, Bl, run_plan(pl, Bl))
+    # wider k ignores the request
+    assert Plan(low, 32).info()["lanes_per_nz"] == 8
+
+
 def test_one_plan_on_two_streams_at_once_is_refused_not_corrupted():
     """include/flex_spmm.h: a plan with split rows owns their workspace, so a launch on a DIFFERENT stream while its latest launch
     is still in flight returns FLEX_ERR_INVALID (and enqueues nothing) instead of silently corrupting those rows; the same stream,

@@ -13,3 +13,8 @@ for cols in 128 64; do
   cat gpurun_out/r04/mfma_kt_$cols/*/*_kernel_stats.csv >> $o 2>/dev/null
 done
 grep -v amdgpu.ids $o
+timeout -k 10 600 python -m pytest tests/test_gpu_spmm.py -x -q -k "narrow_tile or k_sweep or fuzz or widths" 2>&1 | tail -3
+for k in 16 32; do for w in wiki-vote soc-sign-epinions flickr; do
+  python bench.py --workload $w --k $k --steps 200 --no-vendor --no-cpu-baseline --no-copy-probe 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.readlines()[-1]); print('$w k=$k', 'G', j['config']['plan']['lanes_per_nz'], 'us', round(j['roofline']['kernel_ms']*1e3,2), j['roofline'].get('wave_insns_per_64_fma'))"
+  python bench.py --workload $w --k $k --steps 200 --no-vendor --no-cpu-baseline --no-copy-probe --tuning lanes_per_nz=8 2>/dev/null | python -c "import sys,json; j=json.loads(sys.stdin.readlines()[-1]); print('$w k=$k forced G=8', 'G', j['config']['plan']['lanes_per_nz'], 'us', round(j['roofline']['kernel_ms']*1e3,2), j['roofline'].get('wave_insns_per_64_fma'))"
+done; done 2>&1 | tee gpurun_out/r04/narrow_k.txt
