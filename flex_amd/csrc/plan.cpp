@@ -73,8 +73,6 @@ void free_plan_device(flex_plan *p) {
     (void)hipFree(p->d_bk_brow);
     (void)hipFree(p->d_bk_link);
     (void)hipFree(p->d_bk_rec);
-    if (p->done) (void)hipEventDestroy(p->done);
-    p->done = nullptr;
 }
 
 }  // namespace flex
@@ -271,18 +269,24 @@ int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc = FLEX_OK;
     // A plan with split rows owns their partial-sum workspace (and, in the in-launch form, their arrival counters): two launches
-    // of it must not overlap.  Launches on ONE stream are ordered by the stream; a launch on ANOTHER stream while the latest one
-    // has not finished is refused instead of silently corrupting those rows.  (A launch being captured into a graph is neither
-    // checked nor recorded: what replays of the graph overlap with is the caller's to order.)
+    // of it must not overlap.  Launches on ONE stream are ordered by the stream; a launch on ANOTHER stream while the stream of the
+    // latest one still has work pending is refused instead of silently corrupting those rows.  The check is a stream query at the
+    // moment the stream changes -- nothing is added to the launch path of a plan that stays on its stream (an event per launch
+    // cost the Flickr-size launches 2-4 us of device time each).  It is conservative: unrelated work queued behind the plan's launch
+    // on the old stream also counts as pending.  A launch being captured into a graph is neither checked nor remembered.
     bool guard = p->n_partials > 0;
     if (guard) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &cap) != hipSuccess) (void)hipGetLastError();
         if (cap != hipStreamCaptureStatusNone) guard = false;
     }
-    if (guard && p->launched && s != p->last_stream && hipEventQuery(p->done) == hipErrorNotReady) {
-        if (cur != p->device) (void)hipSetDevice(cur);
-        return FLEX_ERR_INVALID;
+    if (guard && p->launched && s != p->last_stream) {
+        const hipError_t q = hipStreamQuery(p->last_stream);
+        if (q == hipErrorNotReady) {
+            if (cur != p->device) (void)hipSetDevice(cur);
+            return FLEX_ERR_INVALID;
+        }
+        if (q != hipSuccess) (void)hipGetLastError();  // e.g. the old stream has been destroyed: nothing of ours can be pending on it
     }
     if (p->bk_blocks && !vec4) {  // block plans exist for the float4 path only, and that needs the 16-byte alignment this header asks for
         if (cur != p->device) (void)hipSetDevice(cur);
@@ -295,14 +299,8 @@ int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream) {
     // the hot blocks' share (the nonzeros with reuse on chip: B rows staged in LDS), added to the rows the flat kernel has written
     if (rc == FLEX_OK && p->bk_blocks) rc = launch_blocks(block_view(p), dB, dC, s);
     if (rc == FLEX_OK && guard) {
-        if (!p->done && hipEventCreateWithFlags(&p->done, hipEventDisableTiming) != hipSuccess) p->done = nullptr;
-        if (p->done && hipEventRecord(p->done, s) == hipSuccess) {
-            p->last_stream = s;
-            p->launched = true;
-        } else {
-            (void)hipGetLastError();
-            p->launched = false;
-        }
+        p->last_stream = s;
+        p->launched = true;
     }
     if (cur != p->device) (void)hipSetDevice(cur);
     return rc;

@@ -63,8 +63,7 @@ struct flex_plan {
     bool has_stats = false;
     flex_plan_stats stats{};
     flex_plan_tuning tuning{};  // the knobs this plan was built with, rules resolved (flex_plan_get_tuning)
-    // in-flight guard of a plan that owns a split-row workspace (flex_spmm): the event marks the end of its latest launch
-    hipEvent_t done = nullptr;
+    // in-flight guard of a plan that owns a split-row workspace (flex_spmm): the stream of its latest launch
     hipStream_t last_stream = nullptr;
     bool launched = false;
 };

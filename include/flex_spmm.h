@@ -190,10 +190,12 @@ int flex_set_host_threads(int n);
  * NOT re-entrant per plan: a plan owns the partial-sum workspace and arrival counters of its split
  * rows, so at most ONE launch of a given plan may be in flight -- do not enqueue the same plan on two
  * streams, or replay two graphs holding it, concurrently (successive launches on one stream are fine;
- * different plans are independent).  Checked for eager launches: a launch on a DIFFERENT stream while the plan's
- * latest launch has not finished returns FLEX_ERR_INVALID and enqueues nothing.  Launches captured into a graph
- * are not checked (nor are replays): ordering those is the caller's.  Plans without split rows
- * (flex_plan_info.n_partials == 0) hold no workspace and may overlap freely. */
+ * different plans are independent).  Checked for eager launches: a launch on a DIFFERENT stream while the stream of the
+ * plan's latest launch still has work pending returns FLEX_ERR_INVALID and enqueues nothing (a stream query when the
+ * stream changes: no cost for a plan that stays on its stream; conservative -- unrelated work queued behind the plan's
+ * launch on the old stream counts as pending too).  Launches captured into a graph are not checked (nor are replays):
+ * ordering those is the caller's.  Plans without split rows (flex_plan_info.n_partials == 0) hold no workspace and may
+ * overlap freely. */
 int flex_spmm(flex_plan *plan, const float *dB, float *dC, flex_stream_t stream);
 
 /* ≙ alpha_freeMatGPU (mat.cuh:184-193). */
