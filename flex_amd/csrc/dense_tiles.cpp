@@ -113,40 +113,27 @@ int detect_dense_tiles(const flex_csr *A, int32_t r0, int32_t m, const std::vect
     } catch (const std::bad_alloc &) {
         return FLEX_ERR_NOMEM;
     }
-    // group directory (second pass over the found list, which is already in (rt, ct) order): a GROUP is two vertically adjacent
-    // row tiles (2g, 2g + 1); its entries are the column tiles either of them holds a dense tile in, in column order, each naming
-    // the upper and / or the lower tile -- the kernel fetches the column tile's B rows once for both
+    // row-tile directory (second pass over the found list, which is already in (rt, ct) order)
     out.rt_ptr.clear();
-    out.gp_ent.clear();
-    out.rt_rows.clear();
-    std::vector<std::pair<uint32_t, uint32_t>> flat;  // (rt, ct) of tile t
+    uint32_t t = 0, last_rt = 0xFFFFFFFFu;
     for (auto &blk : found)
-        for (Found &f : blk) flat.emplace_back(f.rt, f.ct);
-    for (size_t t = 0; t < flat.size();) {
-        const uint32_t g = flat[t].first / 2;
-        size_t u = t;  // tiles of the upper row tile [t, u), of the lower one [u, v)
-        while (u < flat.size() && flat[u].first == 2 * g) ++u;
-        size_t v = u;
-        while (v < flat.size() && flat[v].first == 2 * g + 1) ++v;
-        out.rt_ptr.push_back(static_cast<uint32_t>(out.gp_ent.size()));
-        for (size_t a = t, b = u; a < u || b < v;) {
-            const uint32_t ca = a < u ? flat[a].second : 0xFFFFFFFFu, cb = b < v ? flat[b].second : 0xFFFFFFFFu;
-            if (ca == cb) out.gp_ent.push_back(make_uint2(static_cast<uint32_t>(a++), static_cast<uint32_t>(b++)));
-            else if (ca < cb) out.gp_ent.push_back(make_uint2(static_cast<uint32_t>(a++), kNoTile));
-            else out.gp_ent.push_back(make_uint2(kNoTile, static_cast<uint32_t>(b++)));
-        }
-        for (uint32_t i = 0; i < 64; ++i) {
-            const int64_t sp = static_cast<int64_t>(g) * 64 + i;
-            uint32_t dst = 0xFFFFFFFFu;
-            if (sp < m) {
-                const uint32_t r = sched[sp];
-                dst = dst_map ? static_cast<uint32_t>(dst_map[r]) : r - static_cast<uint32_t>(r0);
+        for (Found &f : blk) {
+            if (f.rt != last_rt) {
+                out.rt_ptr.push_back(t);
+                for (uint32_t i = 0; i < 32; ++i) {
+                    const int64_t sp = static_cast<int64_t>(f.rt) * 32 + i;
+                    uint32_t dst = 0xFFFFFFFFu;
+                    if (sp < m) {
+                        const uint32_t r = sched[sp];
+                        dst = dst_map ? static_cast<uint32_t>(dst_map[r]) : r - static_cast<uint32_t>(r0);
+                    }
+                    out.rt_rows.push_back(dst);
+                }
+                last_rt = f.rt;
             }
-            out.rt_rows.push_back(dst);
+            ++t;
         }
-        t = v;
-    }
-    out.rt_ptr.push_back(static_cast<uint32_t>(out.gp_ent.size()));
+    out.rt_ptr.push_back(t);
     return FLEX_OK;
 }
 

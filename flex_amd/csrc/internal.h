@@ -38,18 +38,14 @@ struct PlanView {
 };
 
 
-// What the dense-tile kernel reads (tile_kernels.hip): 32x32 blocks of A that left the record stream.  Row tiles are taken in
-// GROUPS of two vertically adjacent ones (64 schedule-consecutive rows): the B rows of a column tile that both of them hold a
-// dense tile in are fetched once and feed both tiles' MFMAs.
-constexpr uint32_t kNoTile = 0xFFFFFFFFu;
+// What the dense-tile kernel reads (tile_kernels.hip): 32x32 blocks of A that left the record stream.
 struct TileView {
     const float *a;            // [n_tiles][4][64][4] tile values in MFMA A-operand order: (q,lane,e) = A[lane&31][2(4q+e) + (lane>>5)]
     const uint32_t *boff;      // [n_tiles][32] B row of each tile column: byte offset (off32) or row id
     const uint32_t *mask;      // [n_tiles][32] bit j of word i: the tile holds an entry at (row i, column j) -- an explicit zero counts, an absent one does not
-    const uint32_t *gp_ptr;    // [n_groups+1] entries of each listed group, in column-tile order
-    const uint2 *gp_ent;       // [n_entries] {tile of the group's upper row tile, tile of its lower row tile} at one column tile; kNoTile = none (never both)
-    const uint32_t *gp_rows;   // [n_groups][64] C row of each row of the group, 0xFFFFFFFF = none
-    uint32_t n_groups;
+    const uint32_t *rt_ptr;    // [n_row_tiles+1] tiles of each listed row tile, in column order
+    const uint32_t *rt_rows;   // [n_row_tiles][32] C row of each row of the row tile, 0xFFFFFFFF = none
+    uint32_t n_row_tiles;
 };
 
 // ---- the hot-block path (block_kernels.hip, block_plan.cpp): LDS-level reuse of B for the nonzeros that have it.
@@ -129,7 +125,7 @@ int launch_fixup(const float *partial, const SplitRow *rows, uint32_t n_rows, in
                  hipStream_t s);
 int kernel_attributes(int lanes_per_nz, bool off32, bool vec4, hipFuncAttributes *attr, int *waves_per_cu);
 int launch_gather_rows(float *dst, const float *src, const int32_t *idx, int64_t n, int k, hipStream_t s);
-int launch_tiles(const TileView &tv, bool off32, const float *dB, float *dC, int k, int ldb, int ldc, hipStream_t s, int cols_per_wave = 0);
+int launch_tiles(const TileView &tv, bool off32, const float *dB, float *dC, int k, int ldb, int ldc, hipStream_t s);
 int launch_blocks(const BlockView &bv, const float *dB, float *dC, hipStream_t s);
 
 // FLEX_PLAN_TIMING in the environment: phase times of the planner and the clustering on stderr.  The only environment

@@ -65,7 +65,6 @@ void free_plan_device(flex_plan *p) {
     (void)hipFree(p->d_tile_mask);
     (void)hipFree(p->d_rt_ptr);
     (void)hipFree(p->d_rt_rows);
-    (void)hipFree(p->d_gp_ent);
     (void)hipFree(p->d_bk_hdr);
     (void)hipFree(p->d_bk_wstart);
     (void)hipFree(p->d_bk_cnt);
@@ -295,7 +294,7 @@ int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream) {
     rc = launch_spmm(plan_view(p, fused, p->trace), p->lanes_per_nz, p->off32, vec4, dB, dC, s, p->unroll);
     if (rc == FLEX_OK && !fused) rc = launch_fixup(p->d_partial, p->d_split, p->n_split, p->k, p->ldc, dC, s);
     // the dense tiles' share, added to the rows the kernels above have written
-    if (rc == FLEX_OK && p->n_tiles) rc = launch_tiles(tile_view(p), p->off32, dB, dC, p->k, p->ldb, p->ldc, s, p->tile_cols);
+    if (rc == FLEX_OK && p->n_tiles) rc = launch_tiles(tile_view(p), p->off32, dB, dC, p->k, p->ldb, p->ldc, s);
     // the hot blocks' share (the nonzeros with reuse on chip: B rows staged in LDS), added to the rows the flat kernel has written
     if (rc == FLEX_OK && p->bk_blocks) rc = launch_blocks(block_view(p), dB, dC, s);
     if (rc == FLEX_OK && guard) {

@@ -39,10 +39,8 @@ struct flex_plan {
     bool two_d = false;  // rows cut by column panel (phases), not only by length
     // dense 32x32 tiles routed to the MFMA kernel (tile_kernels.hip)
     float *d_tile_a = nullptr;
-    uint32_t *d_tile_boff = nullptr, *d_tile_mask = nullptr, *d_rt_ptr = nullptr, *d_rt_rows = nullptr;  // rt_*: the GROUP directory (two row tiles each)
-    uint2 *d_gp_ent = nullptr;
-    uint32_t n_tiles = 0, n_row_tiles = 0;  // n_row_tiles: groups listed
-    int tile_cols = 0;                      // columns of C per wave of the tile kernel: 64 or 128
+    uint32_t *d_tile_boff = nullptr, *d_tile_mask = nullptr, *d_rt_ptr = nullptr, *d_rt_rows = nullptr;
+    uint32_t n_tiles = 0, n_row_tiles = 0;
     int64_t tile_nnz = 0;
     int64_t tile_hist[3] = {0, 0, 0}, tile_cells = 0;  // detector report
     bool tile_hist_valid = false;
@@ -113,7 +111,7 @@ inline BlockView block_view(const flex_plan *p) {
     return BlockView{p->d_bk_hdr, p->d_bk_wstart, p->d_bk_cnt, p->d_bk_hcol, p->d_bk_brow, p->d_bk_link, p->d_bk_rec, static_cast<uint64_t>(std::max<int64_t>(p->bk_records, 1)),
                      p->bk_blocks, p->bk_rounds, p->bk_panel_rows, p->k, p->ldb, p->ldc, 1u, p->bk_ablate, p->trace};
 }
-inline TileView tile_view(const flex_plan *p) { return TileView{p->d_tile_a, p->d_tile_boff, p->d_tile_mask, p->d_rt_ptr, p->d_gp_ent, p->d_rt_rows, p->n_row_tiles}; }
+inline TileView tile_view(const flex_plan *p) { return TileView{p->d_tile_a, p->d_tile_boff, p->d_tile_mask, p->d_rt_ptr, p->d_rt_rows, p->n_row_tiles}; }
 // float4 path: k and both strides multiples of 4, both base addresses 16-byte aligned
 inline bool operands_vec4(const flex_plan *p, const float *dB, const float *dC) {
     return (p->k % 4 == 0) && (p->ldb % 4 == 0) && (p->ldc % 4 == 0) &&
@@ -131,9 +129,8 @@ struct DenseTiles {
     std::vector<float> a;           // [T][4][64][4]
     std::vector<uint32_t> boff;     // [T][32]
     std::vector<uint32_t> mask;     // [T][32] which (row, column) cells of the tile hold an entry
-    std::vector<uint32_t> rt_ptr;   // [G+1] entries of each group of two row tiles
-    std::vector<uint2> gp_ent;      // [E] {tile of the upper row tile, tile of the lower one} per (group, column tile); kNoTile = none
-    std::vector<uint32_t> rt_rows;  // [G][64]
+    std::vector<uint32_t> rt_ptr;   // [R+1]
+    std::vector<uint32_t> rt_rows;  // [R][32]
     int64_t nnz = 0;                // entries moved into tiles
     int64_t hist_nnz[3] = {0, 0, 0};
     int64_t n_cells = 0;            // (row tile, column tile) pairs with at least one entry

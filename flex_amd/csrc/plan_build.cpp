@@ -230,8 +230,6 @@ class PlanBuilder {
         const uint32_t fill_pct = static_cast<uint32_t>(std::clamp<long>(pick(tn.mfma_fill_pct, 60), 1, 100));
         p->tuning.mfma = static_cast<int32_t>(mode_mfma);
         p->tuning.mfma_fill_pct = static_cast<int32_t>(fill_pct);
-        p->tile_cols = tn.mfma_cols == 64 || k <= 64 ? 64 : 128;
-        p->tuning.mfma_cols = p->tile_cols;
         const uint32_t thr = (1024u * fill_pct + 99u) / 100u;
         const bool report = (flags & FLEX_PLAN_STATS) != 0;
         const int64_t nnz_in = slice_nnz();
@@ -718,7 +716,6 @@ class PlanBuilder {
             if ((rc = upload(&p->d_tile_mask, tiles.mask, &p->device_bytes))) return rc;
             if ((rc = upload(&p->d_rt_ptr, tiles.rt_ptr, &p->device_bytes))) return rc;
             if ((rc = upload(&p->d_rt_rows, tiles.rt_rows, &p->device_bytes))) return rc;
-            if ((rc = upload(&p->d_gp_ent, tiles.gp_ent, &p->device_bytes))) return rc;
         }
         return FLEX_OK;
     }

@@ -89,7 +89,7 @@ int flex_plan_measure_imbalance(flex_plan *p, const float *dB, float *dC, flex_s
         rc = launch_spmm_stamped(plan_view(p, p->fused_fixup, d_log), p->lanes_per_nz, p->off32, dB, dC, s);
         if (rc == FLEX_OK && !p->fused_fixup) rc = launch_fixup(p->d_partial, p->d_split, p->n_split, p->k, p->ldc, dC, s);
         if (rc == FLEX_OK && p->n_tiles) {
-            rc = launch_tiles(tile_view(p), p->off32, dB, dC, p->k, p->ldb, p->ldc, s, p->tile_cols);
+            rc = launch_tiles(tile_view(p), p->off32, dB, dC, p->k, p->ldb, p->ldc, s);
         }
     }
     if (!rc && (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(log.data(), d_log, words * 8, hipMemcpyDeviceToHost) != hipSuccess)) rc = FLEX_ERR_HIP;
@@ -220,34 +220,21 @@ int flex_plan_self_check(const flex_plan *p) try {
         first += sr.count;
     }
     if (first != p->n_partials) return FLEX_ERR_FORMAT;
-    // dense tiles: the group directory names every tile exactly once (an entry holds the upper and / or the lower row tile's tile at
-    // one column tile; when both, they gather the same B rows), every listed C row is valid and named by one group only, every tile
-    // column names a valid B row
+    // dense tiles: the row-tile directory tiles the tile list, every listed C row is valid and named by one row tile only,
+    // every tile column names a valid B row
     if (p->n_tiles) {
-        const uint32_t ng = p->n_row_tiles;
-        std::vector<uint32_t> gp_ptr(static_cast<size_t>(ng) + 1), gp_rows(static_cast<size_t>(ng) * 64), boff(static_cast<size_t>(p->n_tiles) * 32);
+        std::vector<uint32_t> rt_ptr(static_cast<size_t>(p->n_row_tiles) + 1), rt_rows(static_cast<size_t>(p->n_row_tiles) * 32),
+            boff(static_cast<size_t>(p->n_tiles) * 32);
         if (cur != p->device) FLEX_HIP_TRY(hipSetDevice(p->device));
-        bool ok_t = down(gp_ptr.data(), p->d_rt_ptr, gp_ptr.size() * 4) && down(gp_rows.data(), p->d_rt_rows, gp_rows.size() * 4) &&
-                    down(boff.data(), p->d_tile_boff, boff.size() * 4);
-        std::vector<uint2> ent(ok_t ? gp_ptr[ng] : 0);
-        ok_t = ok_t && down(ent.data(), p->d_gp_ent, ent.size() * sizeof(uint2));
+        const bool ok_t = down(rt_ptr.data(), p->d_rt_ptr, rt_ptr.size() * 4) && down(rt_rows.data(), p->d_rt_rows, rt_rows.size() * 4) &&
+                          down(boff.data(), p->d_tile_boff, boff.size() * 4);
         if (cur != p->device) (void)hipSetDevice(cur);
         if (!ok_t) return FLEX_ERR_HIP;
-        if (gp_ptr[0] != 0 || ent.size() < (p->n_tiles + 1) / 2 || ent.size() > p->n_tiles) return FLEX_ERR_FORMAT;
-        for (uint32_t i = 0; i < ng; ++i)
-            if (gp_ptr[i] >= gp_ptr[i + 1]) return FLEX_ERR_FORMAT;
-        std::vector<uint8_t> named(p->n_tiles, 0);
-        for (const uint2 &e : ent) {
-            if (e.x == kNoTile && e.y == kNoTile) return FLEX_ERR_FORMAT;
-            for (uint32_t t : {e.x, e.y})
-                if (t != kNoTile && (t >= p->n_tiles || named[t]++)) return FLEX_ERR_FORMAT;
-            if (e.x != kNoTile && e.y != kNoTile && !std::equal(boff.begin() + static_cast<size_t>(e.x) * 32, boff.begin() + static_cast<size_t>(e.x) * 32 + 32, boff.begin() + static_cast<size_t>(e.y) * 32))
-                return FLEX_ERR_FORMAT;
-        }
-        for (uint8_t n1 : named)
-            if (n1 != 1) return FLEX_ERR_FORMAT;
+        if (rt_ptr[0] != 0 || rt_ptr[p->n_row_tiles] != p->n_tiles) return FLEX_ERR_FORMAT;
+        for (uint32_t i = 0; i < p->n_row_tiles; ++i)
+            if (rt_ptr[i] >= rt_ptr[i + 1]) return FLEX_ERR_FORMAT;
         std::vector<uint8_t> in_rt(static_cast<size_t>(p->c_rows), 0);
-        for (uint32_t d : gp_rows) {
+        for (uint32_t d : rt_rows) {
             if (d == 0xFFFFFFFFu) continue;
             if (d >= p->c_rows || in_rt[d]++) return FLEX_ERR_FORMAT;
         }

@@ -161,8 +161,7 @@ typedef struct flex_plan_tuning {
                                  column tiles of a group back to back, so that a group's records are re-read from the Infinity Cache rather
                                  than from HBM (0 = rule; 1 = off: one pass over the whole schedule per tile) */
     int32_t xcd_stretch;     /* xcd_slices = 3: workgroups (4 chunks each) per stretch (256) */
-    int32_t mfma_cols;       /* columns of C per wave of the dense-tile kernel: 64 or 128 (rule: 128 for k > 64) */
-    int32_t reserved[7];     /* zero */
+    int32_t reserved[8];     /* zero */
 } flex_plan_tuning;
 
 typedef struct flex_plan_desc {
