@@ -13,9 +13,10 @@
 //   * 16 waves = 15 CONSUMER waves + 1 LOADER wave; one workgroup = one (block, 64-column tile of k), tiles the slow grid dimension.
 //   * A consumer wave is 4 slots of 16 lanes; a slot holds ONE C row per round (ROUNDS rows in all, acc[ROUNDS] float4 per lane:
 //     the lane owns 4 of the tile's 64 columns): no cross-lane reduction, C read once and written once.
-//   * The block's hot B rows are staged panel by panel (up to 304 rows x 256 bytes) by the loader wave with LDS-DMA
-//     (global_load_lds_dwordx4, per-lane source = a row gather) into the other of two buffers while the consumers work on the
-//     current one: one s_barrier per panel.  A slot's ds_read_b128 covers one whole 256-byte row = all 64 banks once, so the
+//   * The block's hot B rows are staged panel by panel (up to 200 rows x 256 bytes) by the loader wave with LDS-DMA
+//     (global_load_lds_dwordx4, per-lane source = a row gather) into a ring of three buffers, two panels ahead of the consumers
+//     (a panel's ~50 DMA instructions need longer to land than its consumers need to use it: with counted vmcnt waits they get
+//     two compute phases); one s_barrier per panel.  A slot's ds_read_b128 covers one whole 256-byte row = all 64 banks once, so the
 //     reads are conflict-free whatever rows the four slots of a wave are on (MI355X_MICROARCH.md, LDS: the 16-lane service
 //     groups hold quarter-rows of different slots, whose banks depend only on the lane).
 //   * Records {offset inside the panel buffer, value} never touch LDS.  The stream of a wave is [step][slot], panel-major; the
@@ -122,20 +123,72 @@ __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_hot_kernel(BlockView
     const uint32_t lane_goff = static_cast<uint32_t>(col_ok ? c0 : t * kBkTileCols) * 4u;
 
     if (w == kBkWaves) {
-        // ---- the loader wave: np + 1 barriers, exactly as many as every consumer wave
-        *reinterpret_cast<uint32_t *>(lds + kBkZeroRow + lane * 4) = 0u;  // the row of zeros (256 bytes) of each buffer that padding records
-        *reinterpret_cast<uint32_t *>(lds + kBkBufBytes + kBkZeroRow + lane * 4) = 0u;  // point at; never written again
+        // ---- the loader wave: np + 1 barriers (+ 1 when rows have several parts), exactly as many as every consumer wave.
+        // It runs kBkNBuf - 1 panels ahead of the consumers.  vmcnt retires in order, so what it waits for is counted in
+        // instructions: H(q) = the DMA of panel q's byte offsets into the scratch (ONE instruction: panel_rows <= 256 on the fast
+        // path), D(q) = the panel's rows (panel_rows / 4 instructions of 1 KiB).  Issue order: ... H(q+1) D(q) H(q+2) D(q+1) ...:
+        // H(q+1) precedes D(q), so waiting for the offsets of the NEXT panel never waits for the rows of this one.
+        for (uint32_t b = 0; b < kBkNBuf; ++b) *reinterpret_cast<uint32_t *>(lds + b * kBkBufBytes + kBkZeroRow + lane * 4) = 0u;  // the rows of zeros padding records point at
         const uint32_t P = v.panel_rows;
         const uint32_t *__restrict__ hcol = v.hcol + hdr.y;
-        dma_hcol(lds, hcol, P, 0, lane);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(v.ablate & 1)) dma_panel(lds, Bb, lane_goff, P, 0, 0, lane);
-        if (np > 1) dma_hcol(lds, hcol + P, P, 1, lane);
-        loader_barrier();  // panel 0 staged (the consumers were fetching their C rows and first records meanwhile)
-        for (uint32_t p = 0; p < np; ++p) {
-            if (p + 1 < np && !(v.ablate & 1)) dma_panel(lds, Bb, lane_goff, P, (p + 1) & 1, (p + 1) & 1, lane);
-            if (p + 2 < np) dma_hcol(lds, hcol + static_cast<uint64_t>(p + 2) * P, P, p & 1, lane);
-            loader_barrier();  // consumers are done with panel p; panel p+1 has landed
+        const bool stage = !(v.ablate & 1);
+        auto H = [&](uint32_t q) { dma_hcol(lds, hcol + static_cast<uint64_t>(q) * P, P, q & 1, lane); };
+        auto D = [&](uint32_t q) {
+            if (stage) dma_panel(lds, Bb, lane_goff, P, q & 1, q % kBkNBuf, lane);
+        };
+        constexpr uint32_t kD = kBkPanelMax / 4;  // instructions of one D on the fast path
+        const bool fast = kBkNBuf == 3 && P == kBkPanelMax && P <= 256 && stage;  // counted waits need compile-time counts
+        if (fast) {
+            // exactly ONE instruction per H (lane 0 is always active): the counts below depend on it
+            auto H = [&](uint32_t q) {
+                if (static_cast<uint32_t>(lane) * 4u < P)
+                    __builtin_amdgcn_global_load_lds((gl_void *)(hcol + static_cast<uint64_t>(q) * P + lane * 4), (lds_void *)(lds + kBkLdsHcol + (q & 1) * (kBkPanelMax * 4)), 16, 0, 0);
+            };
+            // prologue: H0 H1 | D0 H2 | D1, panel 0 landed.  After it: issued ... H(p+2) D(p+1) at the top of iteration p.
+            H(0);
+            if (np > 1) {
+                H(1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1) : "memory");  // H0: behind it H1
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            D(0);
+            if (np > 2) H(2);
+            if (np > 1) {
+                if (np > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kD + 1) : "memory");  // H1: behind it D0 and H2
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kD) : "memory");            //     behind it D0
+                D(1);
+            }
+            if (np > 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kD + 1) : "memory");  // D0: behind it H2 and D1
+            else loader_barrier();
+            for (uint32_t p = 0; p < np; ++p) {
+                if (p + 3 < np) {  // the steady state: H(p+3), D(p+2) go out; D(p+1) must have landed by the barrier
+                    H(p + 3);
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kD + 1) : "memory");  // H(p+2): behind it D(p+1) and H(p+3)
+                    D(p + 2);
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kD + 1) : "memory");  // D(p+1): behind it H(p+3) and D(p+2)
+                } else {           // the last panels: nothing left to count against -- whatever is in flight has to land anyway
+                    if (p + 2 < np) {
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kD) : "memory");  // H(p+2): behind it D(p+1)
+                        D(p + 2);
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kD) : "memory");  // D(p+1): behind it D(p+2)
+                    } else {
+                        loader_barrier();
+                    }
+                }
+            }
+        } else {
+            // any panel size, two or three buffers: one panel ahead, every wait a full drain
+            H(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            D(0);
+            if (np > 1) H(1);
+            loader_barrier();  // panel 0 staged (the consumers were fetching their C rows and first records meanwhile)
+            for (uint32_t p = 0; p < np; ++p) {
+                if (p + 1 < np) D(p + 1);
+                if (p + 2 < np) H(p + 2);
+                loader_barrier();  // consumers are done with panel p; panel p+1 has landed
+            }
         }
         if (chains) loader_barrier();
         return;
@@ -157,11 +210,13 @@ __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_hot_kernel(BlockView
     // step counts of the runs: two 16-bit counts per word, the words held one per lane
     const uint32_t cw = hdr.w;
     const uint32_t *__restrict__ cnt = v.cnt + hdr.z + static_cast<uint64_t>(w) * cw;
-    const uint32_t creg0 = static_cast<uint32_t>(lane) < cw ? cnt[lane] : 0u;
-    const uint32_t creg1 = static_cast<uint32_t>(lane) + 64u < cw ? cnt[lane + 64] : 0u;
-    auto steps_of = [&](uint32_t idx) -> uint32_t {  // idx < 256; 0 past the wave's last run
-        const uint32_t word = idx >> 1;
-        const uint32_t v32 = word < 64 ? __builtin_amdgcn_readlane(creg0, word) : __builtin_amdgcn_readlane(creg1, word - 64);
+    uint32_t creg[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) creg[i] = static_cast<uint32_t>(lane) + 64u * i < cw ? cnt[lane + 64 * i] : 0u;
+    auto steps_of = [&](uint32_t idx) -> uint32_t {  // idx < 512; 0 past the wave's last run
+        const uint32_t word = idx >> 1, l = word & 63u;
+        const uint32_t v32 = word < 128 ? (word < 64 ? __builtin_amdgcn_readlane(creg[0], l) : __builtin_amdgcn_readlane(creg[1], l))
+                                        : (word < 192 ? __builtin_amdgcn_readlane(creg[2], l) : __builtin_amdgcn_readlane(creg[3], l));
         return (idx & 1) ? v32 >> 16 : v32 & 0xFFFFu;
     };
     uint32_t rows[ROUNDS];
@@ -191,7 +246,7 @@ __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_hot_kernel(BlockView
     BK_STAMP(3);
 
     for (uint32_t p = 0; p < np; ++p) {
-        const uint32_t base = (p & 1) * kBkBufBytes + static_cast<uint32_t>(l16) * 16u;
+        const uint32_t base = (p % kBkNBuf) * kBkBufBytes + static_cast<uint32_t>(l16) * 16u;
         const char *panel = lds + base;
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
@@ -247,7 +302,7 @@ __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_hot_kernel(BlockView
         uint32_t link[ROUNDS];
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) link[r] = v.link[((static_cast<uint64_t>(blk) * ROUNDS + r) * kBkWaves + w) * kBkSlots + slot];
-        uint32_t *nxt = reinterpret_cast<uint32_t *>(lds + kBkLdsHcol);  // [rounds x 60] next part + 1
+        uint32_t *nxt = reinterpret_cast<uint32_t *>(lds + kBkLdsNext);  // [rounds x 60] next part + 1
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
             if (link[r] & kBkLinkPart) {

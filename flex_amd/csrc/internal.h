@@ -68,18 +68,24 @@ constexpr int kBkTileCols = 64;                           // columns of C per pa
 constexpr int kBkRowsPerRound = kBkWaves * kBkSlots;      // 60 row slots per round
 constexpr int kBkMaxRounds = 8;
 constexpr uint32_t kBkRunMax = 16;                        // steps of one run = lanes of a slot: what one DPP row holds
-#ifndef FLEX_BK_PANEL_MAX  // experiment builds may vary it; the product has one value
-#define FLEX_BK_PANEL_MAX 304
+#ifndef FLEX_BK_NBUF       // experiment builds (make -C flex_amd/csrc block_variants) may vary the two; the product has one pair
+#define FLEX_BK_NBUF 3
 #endif
+#ifndef FLEX_BK_PANEL_MAX
+#define FLEX_BK_PANEL_MAX (FLEX_BK_NBUF == 2 ? 304 : 200)
+#endif
+constexpr uint32_t kBkNBuf = FLEX_BK_NBUF;                // panel buffers: the loader runs kBkNBuf - 1 panels ahead of the consumers
 constexpr uint32_t kBkPanelMax = FLEX_BK_PANEL_MAX;       // B rows per LDS panel
 constexpr uint32_t kBkRowBytes = 256;                     // one B row of one column tile
 constexpr uint32_t kBkZeroRow = kBkPanelMax * kBkRowBytes; // byte offset, inside a panel buffer, of a row of zeros (padding records point at it)
 constexpr uint32_t kBkBufBytes = kBkZeroRow + kBkRowBytes;
-constexpr uint32_t kBkLdsHcol = 2 * kBkBufBytes;
-constexpr uint32_t kBkLdsBytes = kBkLdsHcol + 2 * kBkPanelMax * 4;  // 158 592 of the CU's 163 840
-static_assert(kBkLdsBytes <= 163840 && kBkPanelMax % 4 == 0 && kBkPanelMax <= 512, "the hot kernel's LDS image must fit one CU");
+constexpr uint32_t kBkLdsHcol = kBkNBuf * kBkBufBytes;    // two scratch slots for the byte offsets of the panels about to be staged
+constexpr uint32_t kBkLdsBytes = kBkLdsHcol + 2 * kBkPanelMax * 4;  // 155 968 of the CU's 163 840 (three buffers of 200 rows)
+static_assert(kBkLdsBytes <= 163840 && kBkPanelMax % 4 == 0 && kBkPanelMax <= 256 + 48 && (kBkNBuf == 2 || kBkNBuf == 3), "the hot kernel's LDS image must fit one CU");
+constexpr uint32_t kBkLdsNext = kBkMaxRounds * kBkRowsPerRound * kBkRowBytes;  // after the last panel: [slots] sums of later parts, then [slots] next part + 1
+static_assert(kBkLdsNext + kBkMaxRounds * kBkRowsPerRound * 4 <= kBkLdsHcol, "the parts of long rows meet in the panel buffers");
 constexpr uint32_t kBkEmptyRow = 0xFFFFFFFFu;             // brow entry of a slot that holds no row
-constexpr uint32_t kBkMaxCounts = 256;                    // panels x rounds step counts per wave, two per lane-held word
+constexpr uint32_t kBkMaxCounts = 512;                    // panels x rounds step counts per wave, two per lane-held word (four words per lane)
 // A long row holds several slots (its PARTS); they meet in LDS after the last panel.  link[slot]: bits 0-15 = 1 + the slot of the
 // row's next part (0 = none), in the block's [round][wave][slot] numbering.
 constexpr uint32_t kBkLinkOwner = 0x40000000u;            // this slot collects the chain that starts at its `next` and writes the row

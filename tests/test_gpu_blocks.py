@@ -50,7 +50,7 @@ def test_hot_blocks_match_the_oracle(k, order):
     assert oracle.rescheck(run_plan(Plan(g, k, order=order, tuning={"blocks": 2}), B), C1, g.rowPtr)[0] == 0
 
 
-@pytest.mark.parametrize("rounds,panel_rows,thr,cap", [(2, 64, 2, 40), (4, 128, 3, 24), (8, 300, 4, 0), (4, 8, 2, 16), (4, 304, 1, 0), (8, 304, 1000000, 0)])
+@pytest.mark.parametrize("rounds,panel_rows,thr,cap", [(2, 64, 2, 40), (4, 128, 3, 24), (8, 196, 4, 0), (4, 8, 2, 16), (4, 200, 1, 0), (8, 200, 1000000, 0)])
 def test_hot_blocks_over_the_knobs(rounds, panel_rows, thr, cap):
     """Every shape of the block image: 2..8 rows per slot, tiny panels (many panels and barriers, the panel budget overflowing into
     the flat plan), thr = 1 (every column staged: runs overflow their 16 steps into the flat plan), a threshold nothing reaches (no

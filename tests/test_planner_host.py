@@ -231,7 +231,7 @@ def test_descriptor_without_the_range_flag_refuses_a_range(sim):
     L.flex_plan_destroy(h)
 
 
-@pytest.mark.parametrize("rounds,panel_rows,thr,cap", [(8, 304, 2, 0), (2, 64, 2, 40), (4, 128, 3, 24), (8, 300, 4, 0), (4, 8, 2, 16)])
+@pytest.mark.parametrize("rounds,panel_rows,thr,cap", [(8, 200, 2, 0), (2, 64, 2, 40), (4, 128, 3, 24), (8, 196, 4, 0), (4, 8, 2, 16)])
 def test_hot_block_plans_are_partitions(sim, rounds, panel_rows, thr, cap):
     """The hot-block route (the matrix is split: nonzeros with reuse inside a block of rounds x 60 rows go to LDS-staged B panels,
     the rest stays with the flat planner; a row longer than `cap` is spread over several slots): the device image must be a partition of the work

@@ -17,7 +17,7 @@ if os.environ.get("PROBE_LIB"):  # an experiment build of the library (make -C f
 from tools._timing import timeit  # noqa: E402
 
 args = sys.argv[1:] or ["reddit", "128"]
-grid = os.environ.get("BLOCK_SWEEP", "8:304:2:0,8:304:3:0,4:304:2:0,8:304:2:0:2,8:304:2:0:3,8:304:2:120,8:304:2:400")  # a 5th field = block_ablate (timing only)
+grid = os.environ.get("BLOCK_SWEEP", "8:0:2:0,8:0:3:0,4:0:2:0,8:0:2:0:2,8:0:2:0:3")  # panel 0 = the build's panel size;  # a 5th field = block_ablate (timing only)
 for name, k in zip(args[0::2], (int(x) for x in args[1::2])):
     gen = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in os.environ.get("GEN", "").split(",") if kv}  # e.g. GEN=p_in=0.75,p_near=0.25
     if gen:
@@ -47,7 +47,7 @@ for name, k in zip(args[0::2], (int(x) for x in args[1::2])):
         i = pb.info()
         t = timeit(pb, B, C, reps)
         err = float((C - ref).abs().max())
-        print(f"{name} k={k} rounds={rounds} panel={prow} thr={thr} cap={pb.tuning()['block_cap']}{' ABLATE=' + str(abl) if abl else ''}: {t:8.1f} us ({t_flat / t:.2f}x)  blocks {i['n_blocks']} rows {100 * i['block_rows'] / ap.m:.1f} % "
+        print(f"{name} k={k} rounds={rounds} panel={pb.tuning()['block_panel_rows']} thr={thr} cap={pb.tuning()['block_cap']}{' ABLATE=' + str(abl) if abl else ''}: {t:8.1f} us ({t_flat / t:.2f}x)  blocks {i['n_blocks']} rows {100 * i['block_rows'] / ap.m:.1f} % "
               f"hot {100 * i['block_hot_nnz'] / ap.nnz:.1f} % of nnz, u={i['block_hot_nnz'] / max(i['block_hot_cols'], 1):.2f} "
               f"panels/block {i['block_panels'] / max(i['n_blocks'], 1):.1f} pad {100 * (i['block_records'] / max(i['block_hot_nnz'], 1) - 1):.1f} % flat records {i['n_records']} plan {tp:.1f} s  max|diff vs flat| {err:.2e}", flush=True)
         pb.destroy()

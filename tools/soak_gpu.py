@@ -40,7 +40,7 @@ KNOBS = {
     # the row-block path (LDS-staged B panels): on for a third of the cases, every shape of its image
     "FLEX_BLOCKS": [None, None, "1"],
     "FLEX_BLOCK_ROUNDS": [None, "2", "4", "8"],
-    "FLEX_BLOCK_PANEL_ROWS": [None, "8", "64", "256", "304"],
+    "FLEX_BLOCK_PANEL_ROWS": [None, "8", "64", "128", "200"],
     "FLEX_BLOCK_THR": [None, "1", "2", "3", "6"],
     "FLEX_BLOCK_CAP": [None, "8", "30", "200"],
 }
