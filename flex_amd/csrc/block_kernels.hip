@@ -13,10 +13,10 @@
 //   * 16 waves = 15 CONSUMER waves + 1 LOADER wave; one workgroup = one (block, 64-column tile of k), tiles the slow grid dimension.
 //   * A consumer wave is 4 slots of 16 lanes; a slot holds ONE C row per round (ROUNDS rows in all, acc[ROUNDS] float4 per lane:
 //     the lane owns 4 of the tile's 64 columns): no cross-lane reduction, C read once and written once.
-//   * The block's hot B rows are staged panel by panel (up to 200 rows x 256 bytes) by the loader wave with LDS-DMA
-//     (global_load_lds_dwordx4, per-lane source = a row gather) into a ring of three buffers, two panels ahead of the consumers
-//     (a panel's ~50 DMA instructions need longer to land than its consumers need to use it: with counted vmcnt waits they get
-//     two compute phases); one s_barrier per panel.  A slot's ds_read_b128 covers one whole 256-byte row = all 64 banks once, so the
+//   * The block's hot B rows are staged panel by panel (up to 304 rows x 256 bytes) by the loader wave with LDS-DMA
+//     (global_load_lds_dwordx4, per-lane source = a row gather) into the other of two buffers while the consumers work on the
+//     current one: one s_barrier per panel.  (An experiment build, -DFLEX_BK_NBUF=3, keeps a ring of three 200-row buffers with the
+//     loader two panels ahead behind counted vmcnt waits: measured slower -- shorter panels mean more runs and more barriers.)  A slot's ds_read_b128 covers one whole 256-byte row = all 64 banks once, so the
 //     reads are conflict-free whatever rows the four slots of a wave are on (MI355X_MICROARCH.md, LDS: the 16-lane service
 //     groups hold quarter-rows of different slots, whose banks depend only on the lane).
 //   * Records {offset inside the panel buffer, value} never touch LDS.  The stream of a wave is [step][slot], panel-major; the

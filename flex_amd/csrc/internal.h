@@ -69,8 +69,8 @@ constexpr int kBkRowsPerRound = kBkWaves * kBkSlots;      // 60 row slots per ro
 constexpr int kBkMaxRounds = 8;
 constexpr uint32_t kBkRunMax = 16;                        // steps of one run = lanes of a slot: what one DPP row holds
 #ifndef FLEX_BK_NBUF       // experiment builds (make -C flex_amd/csrc block_variants) may vary the two; the product has one pair
-#define FLEX_BK_NBUF 3
-#endif
+#define FLEX_BK_NBUF 2     // measured (profiles/r04_hot_block_ring_probe.txt): three buffers of 200 rows with the loader two panels ahead are
+#endif                     // SLOWER than two of 304 -- more panels mean more runs and barriers, and those, not staging latency, are what the kernel pays for
 #ifndef FLEX_BK_PANEL_MAX
 #define FLEX_BK_PANEL_MAX (FLEX_BK_NBUF == 2 ? 304 : 200)
 #endif
@@ -80,7 +80,7 @@ constexpr uint32_t kBkRowBytes = 256;                     // one B row of one co
 constexpr uint32_t kBkZeroRow = kBkPanelMax * kBkRowBytes; // byte offset, inside a panel buffer, of a row of zeros (padding records point at it)
 constexpr uint32_t kBkBufBytes = kBkZeroRow + kBkRowBytes;
 constexpr uint32_t kBkLdsHcol = kBkNBuf * kBkBufBytes;    // two scratch slots for the byte offsets of the panels about to be staged
-constexpr uint32_t kBkLdsBytes = kBkLdsHcol + 2 * kBkPanelMax * 4;  // 155 968 of the CU's 163 840 (three buffers of 200 rows)
+constexpr uint32_t kBkLdsBytes = kBkLdsHcol + 2 * kBkPanelMax * 4;  // 158 592 of the CU's 163 840 (two buffers of 304 rows)
 static_assert(kBkLdsBytes <= 163840 && kBkPanelMax % 4 == 0 && kBkPanelMax <= 256 + 48 && (kBkNBuf == 2 || kBkNBuf == 3), "the hot kernel's LDS image must fit one CU");
 constexpr uint32_t kBkLdsNext = kBkMaxRounds * kBkRowsPerRound * kBkRowBytes;  // after the last panel: [slots] sums of later parts, then [slots] next part + 1
 static_assert(kBkLdsNext + kBkMaxRounds * kBkRowsPerRound * 4 <= kBkLdsHcol, "the parts of long rows meet in the panel buffers");
