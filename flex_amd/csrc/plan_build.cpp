@@ -685,8 +685,31 @@ class PlanBuilder {
                     std::memcpy(&bits, &rval[e], 4);
                     *o++ = make_uint2(p->off32 ? c * row_bytes32 : c, bits);
                 }
-                // pad to a whole number of steps: value 0, B row = the last real one (always a valid address)
-                for (uint2 *end = rec.data() + t_beg[t + 1]; o < end; ++o) *o = make_uint2(o[-1].x, 0u);
+                // Pad to a whole number of steps: B row = the last real one (always a valid address).  The padding does not carry
+                // value 0 -- 0 x inf would turn a row's +-inf into NaN (the oracle and the reference have no padding) -- but SHARES
+                // the last real record's value: v = v/2 + v/4 + ... + v/2^p + v/2^p, every part exact (power-of-two scaling), so a
+                // non-finite B value contributes what v itself would and a finite one the same product up to the last rounding.
+                // Values too small to be halved p times without leaving the normal range keep the plain zero padding.
+                uint2 *const end = rec.data() + t_beg[t + 1];
+                const uint32_t n_pad = static_cast<uint32_t>(end - o);
+                if (n_pad > 0 && pc.end > pc.beg) {
+                    float v;
+                    std::memcpy(&v, &o[-1].y, 4);
+                    const uint32_t ex = (o[-1].y >> 23) & 0xFFu;  // biased exponent of v
+                    if (ex > n_pad + 1 && ex < 0xFFu) {
+                        float part = v;
+                        uint2 *q = o - 1;  // the last real record takes v/2, the paddings v/4 ... v/2^p, v/2^p
+                        for (uint32_t i = 0; i < n_pad; ++i, ++q) {
+                            part *= 0.5f;
+                            uint32_t bits;
+                            std::memcpy(&bits, &part, 4);
+                            q->y = bits;
+                            q[1] = make_uint2(q->x, bits);
+                        }
+                        o = end;
+                    }
+                }
+                for (; o < end; ++o) *o = make_uint2(o[-1].x, 0u);
             }
         });
         pcol = std::vector<uint32_t>();

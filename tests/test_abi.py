@@ -319,3 +319,18 @@ def test_the_library_reads_no_tuning_knob_from_the_environment():
             if "getenv" in code:
                 hits.append((os.path.basename(f), n, code.strip()))
     assert len(hits) == 1 and "FLEX_PLAN_TIMING" in hits[0][2], hits
+
+
+def test_bench_cpu_baseline_reports_the_fastest_thread_count():
+    """bench.py's cpu_baseline leg (the oracle, kind "port"): timed on 16 / 64 / every core the process may use, `value` is the fastest
+    and `cores` the thread count that produced it (on the 256-core GPU box 16 threads beat 256), one thread beside it."""
+    torch = pytest.importorskip("torch")
+    import bench
+    a = flex_amd.synth_graph(n=3000, nnz=3000 + 2 * 20000, community=100, p_in=0.6, p_near=0.2, seed=9)
+    B = torch.rand((a.n, 32)) * 2 - 1
+    out = bench.cpu_baseline(a, 32, B)
+    avail = len(os.sched_getaffinity(0))
+    assert out["kind"] == "port" and out["unit"] == "GFLOPS" and out["value"] > 0 and out["single_thread_value"] > 0
+    assert out["cores_available"] == avail and str(out["cores"]) in out["by_threads"] and set(out["by_threads"]) <= {"16", "64", str(avail)}
+    assert out["value"] >= 0.5 * max(out["by_threads"].values())  # the reported figure is (a re-timing of) the fastest leg
+    assert "the whole workload" in out["sample"]

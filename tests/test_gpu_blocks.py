@@ -114,6 +114,9 @@ def test_hot_blocks_mapped_shards_strides_and_non_finite_values():
     touched = np.zeros(g.m, bool)
     touched[rows[np.isin(g.col, bad)]] = True
     assert np.all(np.isfinite(Cn[~touched])) and not np.all(np.isfinite(Cn[touched]))
+    gold_n = oracle.spmm(g.rowPtr, g.col, g.vals, Bn, nthreads=8)
+    bad_e = ~np.isfinite(gold_n)
+    assert np.array_equal(~np.isfinite(Cn), bad_e) and np.array_equal(Cn[bad_e], gold_n[bad_e], equal_nan=True)  # +-inf stays +-inf, as in the oracle
     clean = ~touched
     assert oracle.rescheck(gold[clean], Cn[clean], np.concatenate([[0], np.cumsum(np.diff(g.rowPtr.astype(np.int64))[clean])]).astype(np.uint32))[0] == 0
     # an unaligned C: block plans need the float4 path (documented), refused rather than computed wrongly

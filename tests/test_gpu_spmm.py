@@ -94,16 +94,24 @@ def test_unsorted_columns_and_duplicates_are_summed():
     assert_matches_oracle(a, B, run_plan(Plan(a, 32), B))
 
 
-def test_inf_nan_only_reach_rows_that_reference_them():
-    a = random_csr(300, 300, 7, seed=5, empty_frac=0.0)
-    B = random_B(300, 128, 6)
+@pytest.mark.parametrize("k", [128, 32, 16, 7])
+def test_inf_nan_only_reach_rows_that_reference_them(k):
+    """Non-finite B values reach exactly the rows that reference them, AS the oracle has them: +-inf stays +-inf (round 4: the
+    padding records of a row share its last value instead of carrying 0, so no 0 x inf = NaN is added to a row's inf), NaN is NaN.
+    Every tile width incl. the narrow one (k = 16) and the generic kernel (k = 7); rows cut into pieces included."""
+    a = random_csr(300, 300, 7, seed=5, empty_frac=0.0, long_rows={40: 290})
+    B = random_B(300, k, 6)
     B[17, :] = np.inf
-    B[18, 5] = np.nan
-    C = run_plan(Plan(a, 128), B)
+    B[18, min(5, k - 1)] = np.nan
+    B[200, 0] = -np.inf
     gold = oracle.spmm(a.rowPtr, a.col, a.vals, B)
-    assert np.array_equal(np.isfinite(C), np.isfinite(gold))
-    fin = np.isfinite(gold)
-    assert np.allclose(C[fin], gold[fin], rtol=1e-5, atol=1e-5)
+    for tuning in (None, {"long_row": 64, "piece_records": 64}):
+        C = run_plan(Plan(a, k, tuning=tuning), B)
+        assert np.array_equal(np.isfinite(C), np.isfinite(gold))
+        fin = np.isfinite(gold)
+        assert np.allclose(C[fin], gold[fin], rtol=1e-5, atol=1e-5)
+        assert np.array_equal(C[~fin], gold[~fin], equal_nan=True)  # inf where the oracle has inf (same sign), NaN where it has NaN
+    assert np.any(np.isinf(gold)) and np.any(np.isnan(gold))
 
 
 def test_rcm_schedule_and_mapped_plan_agree_with_natural():
