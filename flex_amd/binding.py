@@ -78,7 +78,7 @@ class _PlanTuning(C.Structure):  # flex_plan_tuning: every field 0 = the planner
         "lanes_per_nz", "chunk_records", "long_row", "piece_records", "row_cost", "xcd_slices", "xcd_balance",
         "chunk_cost", "task_cost", "split_rows", "rec_nt", "unroll", "two_d", "panel_kb", "seg_min", "mfma",
         "mfma_fill_pct", "lds_extra", "host_threads")] + [("cluster", _ClusterTuning)] + [(f, C.c_int32) for f in (
-        "blocks", "block_rounds", "block_panel_rows", "block_thr", "block_cap", "block_ablate", "tile_group", "xcd_stretch")] + [("reserved", C.c_int32 * 8)]
+        "blocks", "block_rounds", "block_panel_rows", "block_thr", "block_cap", "block_ablate", "tile_group", "xcd_stretch", "far_first")] + [("reserved", C.c_int32 * 7)]
 
 
 TUNING_FIELDS = tuple(f for f, _ in _PlanTuning._fields_ if f not in ("cluster", "reserved"))

@@ -127,7 +127,7 @@ class PlanBuilder {
     std::vector<uint32_t> f_rowptr, f_col;
     std::vector<float> f_vals;
     // knobs
-    uint32_t wave_nnz = 0, row_cost = 16, long_row = 0, piece_len = 0, seg_min = 4, pshift = 0;
+    uint32_t wave_nnz = 0, row_cost = 16, long_row = 0, piece_len = 0, seg_min = 4, pshift = 0, far_window = 0;
     bool two_d = false;
     bool xcd_dealt = false;  // tuning.xcd_slices = 3: stretches of the schedule dealt to the XCDs in turn (build_chunk_table)
     // pieces
@@ -434,6 +434,8 @@ class PlanBuilder {
         pshift = 0;
         while ((2ull << pshift) * tile_bytes <= panel_bytes) ++pshift;  // P = 2^pshift rows of B per panel
         seg_min = static_cast<uint32_t>(pick(tn.seg_min, 4));
+        far_window = two_d ? 0u : static_cast<uint32_t>(std::max(0, tn.far_first));  // (2-D pieces are cut by column panel already)
+        p->tuning.far_first = static_cast<int32_t>(far_window);
         // what this plan was built with (flex_plan_get_tuning)
         flex_plan_tuning &u = p->tuning;
         u.lanes_per_nz = G;
@@ -678,12 +680,31 @@ class PlanBuilder {
                     t_aux[t] = make_uint2(0u, 0u);
                 }
                 uint2 *o = rec.data() + t_beg[t];
-                for (uint32_t e = pc.beg; e < pc.end; ++e) {
+                auto emit_rec = [&](uint32_t e) {
                     uint32_t c = rcol[e];
                     if (col_map) c = static_cast<uint32_t>(col_map[c]);
                     uint32_t bits;
                     std::memcpy(&bits, &rval[e], 4);
                     *o++ = make_uint2(p->off32 ? c * row_bytes32 : c, bits);
+                };
+                if (far_window == 0) {
+                    for (uint32_t e = pc.beg; e < pc.end; ++e) emit_rec(e);
+                } else {
+                    // FAR records first (tuning.far_first): a column whose vertex sits far from the row in the schedule is a likely L2
+                    // miss, a near one a likely hit.  A wave's gathers return in issue order, so a group of U gathers waits for its
+                    // slowest: with misses and hits interleaved nearly every group waits for the fabric, with the misses issued together
+                    // only their groups do.  The order inside each class is kept; the sum order of a row changes, its value within
+                    // rounding, reproducibly.
+                    const auto is_far = [&](uint32_t e) {
+                        const uint32_t c = rcol[e];
+                        const int64_t cp = colpos.empty() ? static_cast<int64_t>(c) : static_cast<int64_t>(colpos[c]);
+                        const int64_t d = cp - static_cast<int64_t>(colpos.empty() ? r : i);
+                        return (d < 0 ? -d : d) > static_cast<int64_t>(far_window);
+                    };
+                    for (uint32_t e = pc.beg; e < pc.end; ++e)
+                        if (is_far(e)) emit_rec(e);
+                    for (uint32_t e = pc.beg; e < pc.end; ++e)
+                        if (!is_far(e)) emit_rec(e);
                 }
                 // Pad to a whole number of steps: B row = the last real one (always a valid address).  The padding does not carry
                 // value 0 -- 0 x inf would turn a row's +-inf into NaN (the oracle and the reference have no padding) -- but SHARES

@@ -161,7 +161,10 @@ typedef struct flex_plan_tuning {
                                  column tiles of a group back to back, so that a group's records are re-read from the Infinity Cache rather
                                  than from HBM (0 = rule; 1 = off: one pass over the whole schedule per tile) */
     int32_t xcd_stretch;     /* xcd_slices = 3: workgroups (4 chunks each) per stretch (256) */
-    int32_t reserved[8];     /* zero */
+    int32_t far_first;       /* > 0: inside every task the records whose column lies more than this many schedule positions from the row come
+                                FIRST (a wave's gathers return in order: with the likely L2 misses issued together, only those groups of
+                                gathers wait for the fabric) (rule: see plan_build.cpp, fill_records) */
+    int32_t reserved[7];     /* zero */
 } flex_plan_tuning;
 
 typedef struct flex_plan_desc {
