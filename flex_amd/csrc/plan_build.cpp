@@ -255,12 +255,12 @@ class PlanBuilder {
         }
         if (tiles.nnz == 0) return FLEX_OK;
         // the vector kernel gets A minus the entries that moved into tiles (same rows, same ids)
-        keep_unmarked(in_tile, static_cast<size_t>(nnz_in - tiles.nnz));
+        keep_unmarked(in_tile);
         return FLEX_OK;
     }
 
     // A := A minus the entries of rows [r0,r1) whose mask byte is set (index e - rowPtr[r0]); same rows, same ids, order kept.
-    void keep_unmarked(const std::vector<uint8_t> &mask, size_t n_keep) {
+    void keep_unmarked(const std::vector<uint8_t> &mask) {
         f_rowptr.assign(static_cast<size_t>(A->m) + 1, 0u);
         const uint32_t eb = A->rowPtr[r0];
         // per-row counts, then the prefix, then a parallel copy (the Amazon shape filters 264 M entries)
@@ -272,7 +272,6 @@ class PlanBuilder {
             }
         });
         for (int32_t r = 0; r < A->m; ++r) f_rowptr[r + 1] += f_rowptr[r];
-        (void)n_keep;
         f_col.resize(f_rowptr[A->m]);
         f_vals.resize(f_rowptr[A->m]);
         const flex_csr *src = A;
@@ -348,7 +347,7 @@ class PlanBuilder {
         p->bk_records = static_cast<int64_t>(img.rec.size());
         p->bk_ablate = static_cast<uint32_t>(tn.block_ablate);
         img = BlockImage{};
-        keep_unmarked(hot_mask, 0);
+        keep_unmarked(hot_mask);
         // what stays flat is a different matrix -- by construction the nonzeros WITHOUT reuse nearby: its tile width and chunk budget
         // follow ITS degree (the Amazon shape's 40 % that stay cold: degree 69, so 64-column tiles and two passes over the records
         // instead of 32-column tiles and four)
