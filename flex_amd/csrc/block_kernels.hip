@@ -338,8 +338,95 @@ __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_hot_kernel(BlockView
 #endif
 }
 
+// The same block image for operands the fast kernel cannot take (B or C not 16-byte aligned: LDS-DMA and the float4 accesses need
+// it): no staging, no DPP -- a lane owns one column of the 64-column tile, reads its records straight from the stream and its B
+// values with 4-byte loads through the panel's offset list.  Same work split (one workgroup per (block, tile), one wave per consumer
+// stream, the parts of a long row meeting in LDS in chain order), so the sums are formed in the same order as in the fast kernel's
+// slots up to the order inside a step; a correctness path, like spmm_generic_kernel for the flat part.
 template <int ROUNDS>
-int launch_rounds(const BlockView &bv, const float *dB, float *dC, hipStream_t s) {
+__global__ __launch_bounds__(64 * kBkWaves) void spmm_hot_generic_kernel(BlockView v, const float *__restrict__ B, float *__restrict__ C) {
+    __shared__ float part_sum[ROUNDS * kBkRowsPerRound][kBkTileCols];  // 480 x 64 floats = 120 KiB at ROUNDS = 8
+    __shared__ uint32_t part_next[ROUNDS * kBkRowsPerRound];
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t blk = blockIdx.x;
+    const uint4 hdr = v.hdr[blk];
+    const uint32_t np = hdr.x & 0x7FFFFFFFu;
+    const bool chains = (hdr.x >> 31) != 0;
+    if (np == 0) return;
+    const int c = blockIdx.y * kBkTileCols + lane;
+    const bool col_ok = c < v.k;
+    const uint32_t P = v.panel_rows;
+    const uint32_t *__restrict__ hcol = v.hcol + hdr.y;
+    const uint2 ws = v.wstart[static_cast<uint64_t>(blk) * kBkWaves + w];
+    const uint2 *__restrict__ rec = v.rec + static_cast<uint64_t>(ws.x) * kBkSlots;
+    const uint32_t cw = hdr.w;
+    const uint32_t *__restrict__ cnt = v.cnt + hdr.z + static_cast<uint64_t>(w) * cw;
+    float acc[ROUNDS][kBkSlots];
+    uint32_t rows[ROUNDS][kBkSlots];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r)
+#pragma unroll
+        for (int sl = 0; sl < kBkSlots; ++sl) {
+            rows[r][sl] = v.brow[((static_cast<uint64_t>(blk) * ROUNDS + r) * kBkWaves + w) * kBkSlots + sl];
+            acc[r][sl] = (rows[r][sl] != kBkEmptyRow && col_ok) ? C[static_cast<uint64_t>(rows[r][sl]) * v.ldc + c] : 0.f;
+        }
+    uint32_t pos = 0;
+    for (uint32_t p = 0; p < np; ++p)
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t idx = p * ROUNDS + r, word = cnt[idx >> 1];
+            const uint32_t n = (idx & 1) ? word >> 16 : word & 0xFFFFu;
+            for (uint32_t j = 0; j < n; ++j, ++pos)
+#pragma unroll
+                for (int sl = 0; sl < kBkSlots; ++sl) {
+                    const uint2 q = rec[static_cast<uint64_t>(pos) * kBkSlots + sl];
+                    if (q.x == kBkZeroRow) continue;  // padding (wave-uniform: the record is the same for every lane)
+                    const uint32_t boff = hcol[static_cast<uint64_t>(p) * P + q.x / kBkRowBytes];
+                    const float b = col_ok ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + boff)[c] : 0.f;
+                    acc[r][sl] = fmaf(__uint_as_float(q.y), b, acc[r][sl]);
+                }
+        }
+    if (chains) {  // workgroup-uniform
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r)
+#pragma unroll
+            for (int sl = 0; sl < kBkSlots; ++sl) {
+                const uint32_t me = (static_cast<uint32_t>(r) * kBkWaves + w) * kBkSlots + sl;
+                const uint32_t l = v.link[static_cast<uint64_t>(blk) * ROUNDS * kBkRowsPerRound + me];
+                if (l & kBkLinkPart) {
+                    part_sum[me][lane] = acc[r][sl];
+                    if (lane == 0) part_next[me] = l & 0xFFFFu;
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r)
+#pragma unroll
+            for (int sl = 0; sl < kBkSlots; ++sl) {
+                const uint32_t me = (static_cast<uint32_t>(r) * kBkWaves + w) * kBkSlots + sl;
+                const uint32_t l = v.link[static_cast<uint64_t>(blk) * ROUNDS * kBkRowsPerRound + me];
+                if (l & kBkLinkOwner) {
+                    uint32_t hops = 0;
+                    for (uint32_t nx = l & 0xFFFFu; nx != 0 && nx <= ROUNDS * kBkRowsPerRound && hops < ROUNDS * kBkRowsPerRound; nx = part_next[nx - 1], ++hops)
+                        acc[r][sl] += part_sum[nx - 1][lane];
+                }
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r)
+#pragma unroll
+        for (int sl = 0; sl < kBkSlots; ++sl)
+            if (rows[r][sl] != kBkEmptyRow && col_ok) C[static_cast<uint64_t>(rows[r][sl]) * v.ldc + c] = acc[r][sl];
+}
+
+template <int ROUNDS>
+int launch_rounds(const BlockView &bv, const float *dB, float *dC, hipStream_t s, bool vec4) {
+    if (!vec4) {
+        hipLaunchKernelGGL((spmm_hot_generic_kernel<ROUNDS>), dim3(bv.n_blocks, (bv.k + kBkTileCols - 1) / kBkTileCols), dim3(64 * kBkWaves), 0, s, bv, dB, dC);
+        FLEX_HIP_TRY(hipGetLastError());
+        return FLEX_OK;
+    }
     const uint32_t nblk = (bv.n_blocks + kXcds - 1) / kXcds * kXcds;
     hipLaunchKernelGGL((spmm_hot_kernel<ROUNDS>), dim3(nblk, (bv.k + kBkTileCols - 1) / kBkTileCols), dim3(64 * (kBkWaves + 1)), 0, s, bv, dB, dC);
     FLEX_HIP_TRY(hipGetLastError());
@@ -348,12 +435,12 @@ int launch_rounds(const BlockView &bv, const float *dB, float *dC, hipStream_t s
 
 }  // namespace
 
-int launch_blocks(const BlockView &bv, const float *dB, float *dC, hipStream_t s) {
+int launch_blocks(const BlockView &bv, const float *dB, float *dC, hipStream_t s, bool vec4) {
     if (bv.n_blocks == 0) return FLEX_OK;
     switch (bv.rounds) {
-        case 2: return launch_rounds<2>(bv, dB, dC, s);
-        case 4: return launch_rounds<4>(bv, dB, dC, s);
-        case 8: return launch_rounds<8>(bv, dB, dC, s);
+        case 2: return launch_rounds<2>(bv, dB, dC, s, vec4);
+        case 4: return launch_rounds<4>(bv, dB, dC, s, vec4);
+        case 8: return launch_rounds<8>(bv, dB, dC, s, vec4);
         default: return FLEX_ERR_UNSUPPORTED;
     }
 }

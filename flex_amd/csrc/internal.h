@@ -132,7 +132,7 @@ int launch_fixup(const float *partial, const SplitRow *rows, uint32_t n_rows, in
 int kernel_attributes(int lanes_per_nz, bool off32, bool vec4, hipFuncAttributes *attr, int *waves_per_cu);
 int launch_gather_rows(float *dst, const float *src, const int32_t *idx, int64_t n, int k, hipStream_t s);
 int launch_tiles(const TileView &tv, bool off32, const float *dB, float *dC, int k, int ldb, int ldc, hipStream_t s);
-int launch_blocks(const BlockView &bv, const float *dB, float *dC, hipStream_t s);
+int launch_blocks(const BlockView &bv, const float *dB, float *dC, hipStream_t s, bool vec4 = true);
 
 // FLEX_PLAN_TIMING in the environment: phase times of the planner and the clustering on stderr.  The only environment
 // variable the library reads; every tuning knob is a field of flex_plan_tuning (include/flex_spmm.h).

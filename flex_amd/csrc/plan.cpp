@@ -287,16 +287,12 @@ int flex_spmm(flex_plan *p, const float *dB, float *dC, flex_stream_t stream) {
         }
         if (q != hipSuccess) (void)hipGetLastError();  // e.g. the old stream has been destroyed: nothing of ours can be pending on it
     }
-    if (p->bk_blocks && !vec4) {  // block plans exist for the float4 path only, and that needs the 16-byte alignment this header asks for
-        if (cur != p->device) (void)hipSetDevice(cur);
-        return FLEX_ERR_UNSUPPORTED;
-    }
     rc = launch_spmm(plan_view(p, fused, p->trace), p->lanes_per_nz, p->off32, vec4, dB, dC, s, p->unroll);
     if (rc == FLEX_OK && !fused) rc = launch_fixup(p->d_partial, p->d_split, p->n_split, p->k, p->ldc, dC, s);
     // the dense tiles' share, added to the rows the kernels above have written
     if (rc == FLEX_OK && p->n_tiles) rc = launch_tiles(tile_view(p), p->off32, dB, dC, p->k, p->ldb, p->ldc, s);
     // the hot blocks' share (the nonzeros with reuse on chip: B rows staged in LDS), added to the rows the flat kernel has written
-    if (rc == FLEX_OK && p->bk_blocks) rc = launch_blocks(block_view(p), dB, dC, s);
+    if (rc == FLEX_OK && p->bk_blocks) rc = launch_blocks(block_view(p), dB, dC, s, vec4);  // unaligned operands: the generic hot kernel
     if (rc == FLEX_OK && guard) {
         p->last_stream = s;
         p->launched = true;

@@ -151,7 +151,7 @@ typedef struct flex_plan_tuning {
        their own kernel after the flat kernel has done the rest) */
     int32_t blocks;           /* 1: split, 2: never (rule: k >= 64 and a very large input -- >= 983 040 rows of average degree >= 48 -- on which
                                  a sampled look finds >= 72 % of the nonzeros in columns that a block of 480 rows uses three times or more;
-                                 needs 16-byte aligned operands: flex_spmm returns FLEX_ERR_UNSUPPORTED for others) */
+                                 operands that are not 16-byte aligned run through generic kernels, correct and slow, as for flat plans) */
     int32_t block_rounds;     /* rows per slot: 2, 4 or 8; a block is rounds x 60 rows (8; 4 / 2 while there are few blocks per CU) */
     int32_t block_panel_rows; /* B rows per LDS panel: a multiple of 4, at most 304 (304) */
     int32_t block_thr;        /* a column is hot (staged) when at least this many nonzeros of the block use it (3) */

@@ -119,10 +119,18 @@ def test_hot_blocks_mapped_shards_strides_and_non_finite_values():
     assert np.array_equal(~np.isfinite(Cn), bad_e) and np.array_equal(Cn[bad_e], gold_n[bad_e], equal_nan=True)  # +-inf stays +-inf, as in the oracle
     clean = ~touched
     assert oracle.rescheck(gold[clean], Cn[clean], np.concatenate([[0], np.cumsum(np.diff(g.rowPtr.astype(np.int64))[clean])]).astype(np.uint32))[0] == 0
-    # an unaligned C: block plans need the float4 path (documented), refused rather than computed wrongly
+    # unaligned operands (C and B one float off a 16-byte boundary): the fast kernels need the alignment; the generic pair -- the
+    # flat part's and the hot blocks' -- takes over and the result is as right (round 3 refused such a launch)
+    pu = Plan(g, k, order=flex_amd.FLEX_ORDER_CLUSTER, tuning=BLOCKS)
+    assert pu.info()["n_blocks"] > 0
     Cu = torch.empty(g.m * k + 1, device="cuda")[1:]
-    with pytest.raises(flex_amd.FlexError):
-        Plan(g, k, tuning=BLOCKS).spmm(dev(B).data_ptr(), Cu.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    Bu = torch.empty(g.n * k + 1, device="cuda")[1:]
+    Bu.copy_(dev(B).reshape(-1))
+    for b_ptr, c_t in ((dev(B).data_ptr(), Cu), (Bu.data_ptr(), torch.empty(g.m * k, device="cuda")), (Bu.data_ptr(), Cu)):
+        c_t.fill_(float("nan"))
+        pu.spmm(b_ptr, c_t.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert oracle.rescheck(gold, c_t.cpu().numpy().reshape(g.m, k), g.rowPtr)[0] == 0
 
 
 def test_hot_blocks_are_stable_under_repetition():
