@@ -738,6 +738,26 @@ def test_narrow_tile_for_k_up_to_16(knobs, k, split_rows):
     assert Plan(low, 32).info()["lanes_per_nz"] == 8
 
 
+def test_far_records_first_is_a_reordering_inside_tasks_only(knobs):
+    """tuning.far_first: inside every task the records whose column lies far from the row in the schedule come first (measured: no
+    effect on launch time, profiles/r04_far_first_probe.txt; the knob stays for experiments).  Same plan shape, same result within
+    the tolerance, for a whole plan, a mapped plan and pieces of long rows."""
+    g = flex_amd.synth_graph(n=20000, nnz=20000 + 2 * 400000, community=300, p_in=0.6, p_near=0.25, seed=31)
+    B = random_B(g.n, 128, 4)
+    base = Plan(g, 128, order=flex_amd.FLEX_ORDER_CLUSTER)
+    C0 = run_plan(base, B)
+    gold, _ = assert_matches_oracle(g, B, C0)
+    knobs.set(far_first=600)
+    p = Plan(g, 128, order=flex_amd.FLEX_ORDER_CLUSTER)
+    assert p.tuning()["far_first"] == 600 and p.info()["n_records"] == base.info()["n_records"] and p.info()["n_chunks"] == base.info()["n_chunks"]
+    p.self_check()
+    C1 = run_plan(p, B)
+    assert oracle.rescheck(gold, C1, g.rowPtr)[0] == 0 and not np.array_equal(C0, C1)  # the sum order of a row did change
+    vo, gp = flex_amd.perm_csr(g, flex_amd.order_cluster(g))
+    knobs.set(long_row=64, piece_records=64)
+    assert oracle.rescheck(gold, run_plan(Plan(gp, 128, vo_mp=vo), B), g.rowPtr)[0] == 0
+
+
 def test_one_plan_on_two_streams_at_once_is_refused_not_corrupted():
     """include/flex_spmm.h: a plan with split rows owns their workspace, so a launch on a DIFFERENT stream while its latest launch
     is still in flight returns FLEX_ERR_INVALID (and enqueues nothing) instead of silently corrupting those rows; the same stream,

@@ -231,6 +231,23 @@ def test_descriptor_without_the_range_flag_refuses_a_range(sim):
     L.flex_plan_destroy(h)
 
 
+def test_far_first_reorders_records_inside_tasks(sim):
+    """tuning.far_first only permutes the records of each task: same tasks, chunks and record count, a different image, still a partition."""
+    g = flex_amd.synth_graph(n=12000, nnz=12000 + 2 * 240000, community=300, p_in=0.6, p_near=0.25, seed=12)
+    sim.hostsim_upload_hash.restype = C.c_uint64
+    sim.hostsim_upload_hash.argtypes = [C.c_int]
+    shapes, images = [], []
+    for far in (0, 500):
+        sim.hostsim_upload_hash(1)
+        p = flex_amd.Plan(g, 128, order=flex_amd.FLEX_ORDER_CLUSTER, tuning={"far_first": far})
+        images.append(sim.hostsim_upload_hash(1))
+        p.self_check()
+        i = p.info()
+        shapes.append((i["n_tasks"], i["n_chunks"], i["n_records"], i["n_partials"]))
+        assert p.tuning()["far_first"] == far
+    assert shapes[0] == shapes[1] and images[0] != images[1]
+
+
 @pytest.mark.parametrize("rounds,panel_rows,thr,cap", [(8, 200, 2, 0), (2, 64, 2, 40), (4, 128, 3, 24), (8, 196, 4, 0), (4, 8, 2, 16)])
 def test_hot_block_plans_are_partitions(sim, rounds, panel_rows, thr, cap):
     """The hot-block route (the matrix is split: nonzeros with reuse inside a block of rounds x 60 rows go to LDS-staged B panels,
