@@ -226,14 +226,15 @@ __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_hot_kernel(BlockView
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {  // the flat kernel's part of the row: this kernel adds to it
         const uint32_t row = rows[r] == kBkEmptyRow ? 0u : rows[r];
-        const v4f cur = *reinterpret_cast<const v4f *>(C + static_cast<uint64_t>(row) * v.ldc + (col_ok ? c0 : 0));
+        v4f cur = {0.f, 0.f, 0.f, 0.f};
+        if (!(v.ablate & 16)) cur = *reinterpret_cast<const v4f *>(C + static_cast<uint64_t>(row) * v.ldc + (col_ok ? c0 : 0));  // (wave-uniform; timing-only)
         acc[r] = (rows[r] != kBkEmptyRow && col_ok) ? cur : v4f{0.f, 0.f, 0.f, 0.f};
     }
     // run r of the next panel is fetched as soon as run r of this one is done with its registers: one panel of lead
     uint32_t rx[ROUNDS], ry[ROUNDS];
     uint32_t pos_pf = 0;  // step (wave-relative) at which the next run to fetch begins
     auto fetch_run = [&](int r, uint32_t run_idx) {
-        const uint32_t idx = min((pos_pf + static_cast<uint32_t>(l16)) * kBkSlots + slot, last_rec);
+        const uint32_t idx = (v.ablate & 32) ? static_cast<uint32_t>(lane) : min((pos_pf + static_cast<uint32_t>(l16)) * kBkSlots + slot, last_rec);  // 32: timing-only, one hot line
         const v2u q = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(rec + idx));  // read once per tile
         rx[r] = q.x;
         ry[r] = q.y;
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_hot_kernel(BlockView
     }
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r)
-        if (rows[r] != kBkEmptyRow && col_ok) *reinterpret_cast<v4f *>(C + static_cast<uint64_t>(rows[r]) * v.ldc + c0) = acc[r];
+        if (rows[r] != kBkEmptyRow && col_ok && !(v.ablate & 16)) *reinterpret_cast<v4f *>(C + static_cast<uint64_t>(rows[r]) * v.ldc + c0) = acc[r];
 #ifdef FLEX_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     BK_STAMP(5);

@@ -103,7 +103,7 @@ struct BlockView {
     uint32_t n_blocks, rounds, panel_rows;
     int32_t k, ldb, ldc;
     uint32_t xcd_remap;
-    uint32_t ablate;         // timing-only (tools/probe_blocks.py; results are WRONG): 1 no panel DMA, 2 no panel work
+    uint32_t ablate;         // timing-only (tools/probe_blocks.py; results are WRONG): 1 no panel DMA, 2 no panel work, 16 no read-modify-write of C, 32 every record load hits one line
     uint64_t *trace;         // -DFLEX_TRACE builds only (tools/trace_blocks.py): 8 cycle counters per (tile, block, wave); else nullptr
 };
 

@@ -156,7 +156,7 @@ typedef struct flex_plan_tuning {
     int32_t block_panel_rows; /* B rows per LDS panel: a multiple of 4, at most 304 (304) */
     int32_t block_thr;        /* a column is hot (staged) when at least this many nonzeros of the block use it (3) */
     int32_t block_cap;        /* nonzeros per slot: a longer row is spread over ceil(len / cap) slots, summed through LDS (1.5 x the average degree) */
-    int32_t block_ablate;     /* timing-only experiments, the RESULT IS WRONG: 1 no panel staging, 2 no panel work */
+    int32_t block_ablate;     /* timing-only experiments, the RESULT IS WRONG: 1 no panel staging, 2 no panel work, 16 no read-modify-write of C, 32 record loads folded onto one line */
     int32_t tile_group;       /* multi-tile launches: workgroups per group -- every XCD's slice of the schedule is walked group by group, all
                                  column tiles of a group back to back, so that a group's records are re-read from the Infinity Cache rather
                                  than from HBM (0 = rule; 1 = off: one pass over the whole schedule per tile) */
