@@ -210,15 +210,10 @@ __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_hot_kernel(BlockView
     // step counts of the runs: two 16-bit counts per word, the words held one per lane
     const uint32_t cw = hdr.w;
     const uint32_t *__restrict__ cnt = v.cnt + hdr.z + static_cast<uint64_t>(w) * cw;
-    uint32_t creg[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) creg[i] = static_cast<uint32_t>(lane) + 64u * i < cw ? cnt[lane + 64 * i] : 0u;
-    auto steps_of = [&](uint32_t idx) -> uint32_t {  // idx < 512; 0 past the wave's last run
-        const uint32_t word = idx >> 1, l = word & 63u;
-        const uint32_t v32 = word < 128 ? (word < 64 ? __builtin_amdgcn_readlane(creg[0], l) : __builtin_amdgcn_readlane(creg[1], l))
-                                        : (word < 192 ? __builtin_amdgcn_readlane(creg[2], l) : __builtin_amdgcn_readlane(creg[3], l));
-        return (idx & 1) ? v32 >> 16 : v32 & 0xFFFFu;
-    };
+    // run counts: lane p holds panel p's 64-bit word (byte r = steps of round r); lanes past the last panel hold 0
+    const bool has_cnt = static_cast<uint32_t>(lane) < np;
+    const uint32_t c_lo = has_cnt ? cnt[2 * lane] : 0u, c_hi = has_cnt ? cnt[2 * lane + 1] : 0u;
+    auto count_of = [](uint32_t lo, uint32_t hi, int r) -> uint32_t { return ((r < 4 ? lo : hi) >> (8 * (r & 3))) & 0xFFu; };
     uint32_t rows[ROUNDS];
     v4f acc[ROUNDS];
 #pragma unroll
@@ -233,15 +228,18 @@ __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_hot_kernel(BlockView
     // run r of the next panel is fetched as soon as run r of this one is done with its registers: one panel of lead
     uint32_t rx[ROUNDS], ry[ROUNDS];
     uint32_t pos_pf = 0;  // step (wave-relative) at which the next run to fetch begins
-    auto fetch_run = [&](int r, uint32_t run_idx) {
+    auto fetch_run = [&](int r, uint32_t n_run) {  // n_run: the steps of the run being fetched (the next one starts behind it)
         const uint32_t idx = (v.ablate & 32) ? static_cast<uint32_t>(lane) : min((pos_pf + static_cast<uint32_t>(l16)) * kBkSlots + slot, last_rec);  // 32: timing-only, one hot line
         const v2u q = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(rec + idx));  // read once per tile
         rx[r] = q.x;
         ry[r] = q.y;
-        pos_pf += steps_of(run_idx);
+        pos_pf += n_run;
     };
+    {
+        const uint32_t lo = __builtin_amdgcn_readlane(c_lo, 0), hi = __builtin_amdgcn_readlane(c_hi, 0);
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) fetch_run(r, static_cast<uint32_t>(r));
+        for (int r = 0; r < ROUNDS; ++r) fetch_run(r, count_of(lo, hi, r));
+    }
     BK_STAMP(0);
     consumer_barrier();  // panel 0 has landed
     BK_STAMP(3);
@@ -249,9 +247,12 @@ __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_hot_kernel(BlockView
     for (uint32_t p = 0; p < np; ++p) {
         const uint32_t base = (p % kBkNBuf) * kBkBufBytes + static_cast<uint32_t>(l16) * 16u;
         const char *panel = lds + base;
+        // this panel's eight run counts and the next panel's (lane np holds 0): four v_readlane per panel, a bit-field extract per run
+        const uint32_t lo = __builtin_amdgcn_readlane(c_lo, p), hi = __builtin_amdgcn_readlane(c_hi, p);
+        const uint32_t nlo = __builtin_amdgcn_readlane(c_lo, p + 1), nhi = __builtin_amdgcn_readlane(c_hi, p + 1);
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
-            const uint32_t n = (v.ablate & 2) ? 0u : steps_of(p * ROUNDS + r);
+            const uint32_t n = (v.ablate & 2) ? 0u : count_of(lo, hi, r);
             const uint32_t x = rx[r], y = ry[r];
             v4f a = acc[r];
             // four steps at a time while the run has them (wave-uniform branches; step indices are compile-time: DPP controls are immediates)
@@ -284,14 +285,18 @@ __global__ __launch_bounds__(64 * (kBkWaves + 1)) void spmm_hot_kernel(BlockView
         }                                                                                            \
     }
             { BK_QUAD(0) }
-            { BK_QUAD(1) }
-            { BK_QUAD(2) }
-            { BK_QUAD(3) }
+            if (n > 4) {  // most runs are done after one group of four steps: one branch skips the other three
+                { BK_QUAD(1) }
+                if (n > 8) {
+                    { BK_QUAD(2) }
+                    { BK_QUAD(3) }
+                }
+            }
 #undef BK_QUAD
 #undef BK_STEP
             acc[r] = a;
             // unconditional (an index past the stream is clamped, its count is 0): a load inside a branch costs an s_waitcnt vmcnt(0)
-            fetch_run(r, (p + 1) * ROUNDS + static_cast<uint32_t>(r));
+            fetch_run(r, count_of(nlo, nhi, r));
         }
         BK_STAMP(2);
         consumer_barrier();
@@ -376,8 +381,7 @@ __global__ __launch_bounds__(64 * kBkWaves) void spmm_hot_generic_kernel(BlockVi
     for (uint32_t p = 0; p < np; ++p)
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
-            const uint32_t idx = p * ROUNDS + r, word = cnt[idx >> 1];
-            const uint32_t n = (idx & 1) ? word >> 16 : word & 0xFFFFu;
+            const uint32_t n = (cnt[2 * p + r / 4] >> (8 * (r & 3))) & 0xFFu;
             for (uint32_t j = 0; j < n; ++j, ++pos)
 #pragma unroll
                 for (int sl = 0; sl < kBkSlots; ++sl) {

@@ -17,7 +17,7 @@
 //                           becomes a record {byte offset inside the panel buffer, value} of (slot, panel);
 //                           slots with similar panel profiles are grouped 4 to a (wave, round), groups dealt to the 15 waves by
 //                           longest-processing-time; a RUN (wave, panel, round) is as long as its longest slot (<= 16 steps)
-//   emit                    per wave ONE record stream [step][slot], panel-major; 16-bit step counts per run
+//   emit                    per wave ONE record stream [step][slot], panel-major; per (wave, panel) the 8-bit step counts of its runs
 //
 // The image does not depend on the number of host threads (blocks are independent and concatenated in order).
 #include <algorithm>
@@ -80,7 +80,7 @@ int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const st
                  const int32_t *dst_map, int32_t r0, uint32_t row_bytes32, const BlockKnobs &kn, BlockImage &img, std::vector<uint8_t> &hot_mask) {
     const int64_t m = static_cast<int64_t>(sched.size());
     const uint32_t rounds = kn.rounds, P = kn.panel_rows, RB = rounds * kBkRowsPerRound;
-    const uint32_t max_panels = std::min<uint32_t>(kn.max_panels, kBkMaxCounts / rounds - 1);
+    const uint32_t max_panels = std::min<uint32_t>(kn.max_panels, kBkMaxPanels);
     const uint32_t run_max = std::min<uint32_t>(std::max<uint32_t>(kn.run_max, 1u), kBkRunMax);
     img = BlockImage{};
     img.rounds = rounds;
@@ -304,7 +304,7 @@ int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const st
             }
             if (n_chain) o.link[own] |= kBkLinkOwner;
         }
-        const uint32_t cw = (np * rounds + 1) / 2;
+        const uint32_t cw = 2 * np;  // per wave and panel one 64-bit word: byte r = the steps of the run (panel, round r)
         o.cnt.assign(static_cast<size_t>(kBkWaves) * cw, 0u);
         uint32_t step_pos = 0;
         for (uint32_t w = 0; w < kBkWaves; ++w) {
@@ -314,8 +314,7 @@ int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const st
                     const uint32_t g = grp_of[static_cast<size_t>(w) * rounds + rd];
                     uint32_t steps = 0;
                     for (uint32_t s = 0; s < kBkSlots; ++s) steps = std::max(steps, cnt_sp(g * kBkSlots + s, ph));
-                    const uint32_t idx = ph * rounds + rd;
-                    o.cnt[static_cast<size_t>(w) * cw + idx / 2] |= steps << (16 * (idx & 1));
+                    o.cnt[static_cast<size_t>(w) * cw + 2 * ph + rd / 4] |= steps << (8 * (rd & 3));
                     const size_t base = o.rec.size();
                     o.rec.resize(base + static_cast<size_t>(steps) * kBkSlots);
                     for (uint32_t s = 0; s < kBkSlots; ++s) {
@@ -339,7 +338,7 @@ int build_blocks(const flex_csr *A, const std::vector<uint32_t> &sched, const st
     std::vector<uint64_t> rec_at(static_cast<size_t>(nb) + 1, 0), cnt_at(static_cast<size_t>(nb) + 1, 0), hcol_at(static_cast<size_t>(nb) + 1, 0);
     for (int64_t b = 0; b < nb; ++b) {
         const BlockOut &o = out[static_cast<size_t>(b)];
-        if (o.hdr.w * 2 > kBkMaxCounts || (o.hdr.x & 0x7FFFFFFFu) > max_panels) return FLEX_ERR_UNSUPPORTED;  // cannot happen: max_panels bounds both
+        if ((o.hdr.x & 0x7FFFFFFFu) > max_panels) return FLEX_ERR_UNSUPPORTED;  // cannot happen: max_panels bounds both
         rec_at[b + 1] = rec_at[b] + o.rec.size();
         cnt_at[b + 1] = cnt_at[b] + o.cnt.size();
         hcol_at[b + 1] = hcol_at[b] + o.hcol.size();

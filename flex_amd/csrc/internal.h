@@ -85,16 +85,16 @@ static_assert(kBkLdsBytes <= 163840 && kBkPanelMax % 4 == 0 && kBkPanelMax <= 25
 constexpr uint32_t kBkLdsNext = kBkMaxRounds * kBkRowsPerRound * kBkRowBytes;  // after the last panel: [slots] sums of later parts, then [slots] next part + 1
 static_assert(kBkLdsNext + kBkMaxRounds * kBkRowsPerRound * 4 <= kBkLdsHcol, "the parts of long rows meet in the panel buffers");
 constexpr uint32_t kBkEmptyRow = 0xFFFFFFFFu;             // brow entry of a slot that holds no row
-constexpr uint32_t kBkMaxCounts = 512;                    // panels x rounds step counts per wave, two per lane-held word (four words per lane)
+constexpr uint32_t kBkMaxPanels = 63;                     // a wave holds its run counts one panel per lane (and looks one panel ahead)
 // A long row holds several slots (its PARTS); they meet in LDS after the last panel.  link[slot]: bits 0-15 = 1 + the slot of the
 // row's next part (0 = none), in the block's [round][wave][slot] numbering.
 constexpr uint32_t kBkLinkOwner = 0x40000000u;            // this slot collects the chain that starts at its `next` and writes the row
 constexpr uint32_t kBkLinkPart = 0x80000000u;             // this slot publishes its sum (and its `next`) for the owner
 
 struct BlockView {
-    const uint4 *hdr;        // [n_blocks] {panels | (some row has several parts) << 31, first entry in hcol, first word in cnt, words of cnt per wave}
+    const uint4 *hdr;        // [n_blocks] {panels | (some row has several parts) << 31, first entry in hcol, first word in cnt, words of cnt per wave (2 x panels)}
     const uint2 *wstart;     // [n_blocks][15] {first step of the wave's record stream, its steps}
-    const uint32_t *cnt;     // per (block, wave): 16-bit step counts of its runs, panel-major [panels][rounds], two per word
+    const uint32_t *cnt;     // per (block, wave, panel): a 64-bit word (two u32), byte r = the steps (<= 16) of the run (panel, round r)
     const uint32_t *hcol;    // per (block, panel): panel_rows byte offsets of the B rows staged (padded with a valid one)
     const uint32_t *brow;    // [n_blocks][rounds][15][4] C row the slot reads and writes (an owner); kBkEmptyRow = none (empty, or a later part of a row)
     const uint32_t *link;    // [n_blocks][rounds][15][4] kBkLinkOwner / kBkLinkPart | next part + 1; 0 for a row of one part

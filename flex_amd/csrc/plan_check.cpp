@@ -273,7 +273,7 @@ int flex_plan_self_check(const flex_plan *p) try {
             h.x &= 0x7FFFFFFFu;
             if (h.x == 0) {
                 if (h.w != 0 || chains) return FLEX_ERR_FORMAT;
-            } else if (h.y != at_hcol || h.z != at_cnt || h.w != (h.x * rounds + 1) / 2 || h.x * rounds + rounds > kBkMaxCounts || h.y % 4 != 0) {
+            } else if (h.y != at_hcol || h.z != at_cnt || h.w != 2 * h.x || h.x > kBkMaxPanels || h.y % 4 != 0) {
                 return FLEX_ERR_FORMAT;
             }
             at_hcol += static_cast<uint64_t>(h.x) * P;
@@ -283,9 +283,10 @@ int flex_plan_self_check(const flex_plan *p) try {
                 const uint2 ws = wstart[static_cast<size_t>(b) * kBkWaves + w];
                 if (ws.x != at_step) return FLEX_ERR_FORMAT;
                 uint64_t pos = static_cast<uint64_t>(ws.x) * kBkSlots, steps = 0;
-                for (uint32_t idx = 0; idx < h.x * rounds; ++idx) {
-                    const uint32_t word = cnt[h.z + static_cast<size_t>(w) * h.w + idx / 2];
-                    const uint32_t n = (idx & 1) ? word >> 16 : word & 0xFFFFu;
+                for (uint32_t idx = 0; idx < h.x * kBkMaxRounds; ++idx) {  // panel-major, eight byte counts per panel (rounds beyond the block's: 0)
+                    const uint32_t ph = idx / kBkMaxRounds, rd = idx % kBkMaxRounds;
+                    const uint32_t n = (cnt[h.z + static_cast<size_t>(w) * h.w + 2 * ph + rd / 4] >> (8 * (rd & 3))) & 0xFFu;
+                    if (rd >= rounds && n != 0) return FLEX_ERR_FORMAT;
                     if (n > kBkRunMax || pos + static_cast<uint64_t>(n) * kBkSlots > brec.size()) return FLEX_ERR_FORMAT;
                     for (uint64_t q = 0; q < static_cast<uint64_t>(n) * kBkSlots; ++q) {
                         const uint2 r = brec[pos + q];
