@@ -387,7 +387,8 @@ def main():
                 "plan": {"chunks": info["n_chunks"], "tasks": info["n_tasks"], "split_rows": info["n_split_rows"],
                          "lanes_per_nz": info["lanes_per_nz"], "two_d": info["two_d"], "mfma_tiles": info["n_tiles"],
                          "blocks": info.get("n_blocks", 0), "block_hot_nnz": info.get("block_hot_nnz", 0), "block_hot_cols": info.get("block_hot_cols", 0),
-                         "block_records": info.get("block_records", 0), "block_panels": info.get("block_panels", 0), "plan_s": round(t_plan, 3), "order_s": round(timings["order_s"], 3),
+                         "block_records": info.get("block_records", 0), "block_panels": info.get("block_panels", 0),
+                         "bundles": info.get("n_bundles", 0), "bundle_rows": info.get("bundle_rows", 0), "records": info.get("n_records", 0), "plan_s": round(t_plan, 3), "order_s": round(timings["order_s"], 3),
                          "gen_s": round(t_gen, 3), "host_threads": host_threads, "perm_cache": cache_state},
                 "b_bcast_ms": round(bcast_ms, 3),
                 # ≙ the README's "tPre/tElap" column (README.md:34-42): preprocessing (ordering + planning + upload) over

@@ -54,7 +54,8 @@ class _PlanInfo(C.Structure):  # flex_plan_info
                 ("plan_ms", C.c_double), ("n_slots", C.c_int64), ("two_d", C.c_int32), ("panel_rows", C.c_int32),
                 ("n_tiles", C.c_int64), ("tile_nnz", C.c_int64), ("n_records", C.c_int64),
                 ("n_blocks", C.c_int64), ("block_rows", C.c_int64), ("block_nnz", C.c_int64), ("block_hot_nnz", C.c_int64),
-                ("block_hot_cols", C.c_int64), ("block_panels", C.c_int64), ("block_records", C.c_int64)]
+                ("block_hot_cols", C.c_int64), ("block_panels", C.c_int64), ("block_records", C.c_int64),
+                ("n_bundles", C.c_int64), ("bundle_rows", C.c_int64)]
 
 
 class _PlanStats(C.Structure):  # flex_plan_stats
@@ -78,7 +79,7 @@ class _PlanTuning(C.Structure):  # flex_plan_tuning: every field 0 = the planner
         "lanes_per_nz", "chunk_records", "long_row", "piece_records", "row_cost", "xcd_slices", "xcd_balance",
         "chunk_cost", "task_cost", "split_rows", "rec_nt", "unroll", "two_d", "panel_kb", "seg_min", "mfma",
         "mfma_fill_pct", "lds_extra", "host_threads")] + [("cluster", _ClusterTuning)] + [(f, C.c_int32) for f in (
-        "blocks", "block_rounds", "block_panel_rows", "block_thr", "block_cap", "block_ablate", "tile_group", "xcd_stretch", "far_first")] + [("reserved", C.c_int32 * 7)]
+        "blocks", "block_rounds", "block_panel_rows", "block_thr", "block_cap", "block_ablate", "tile_group", "xcd_stretch", "far_first", "bundle", "bundle_len")] + [("reserved", C.c_int32 * 5)]
 
 
 TUNING_FIELDS = tuple(f for f, _ in _PlanTuning._fields_ if f not in ("cluster", "reserved"))

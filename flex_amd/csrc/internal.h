@@ -18,8 +18,10 @@ struct SplitRow {
 struct PlanView {
     const uint2 *rec;        // [nnz] {x = B-row byte offset (off32) or column id, y = value bits}, task order
     const uint32_t *t_beg;   // [n_tasks+1] first record of each task
-    const uint32_t *t_dst;   // [n_tasks]   C row written by the task; MSB set -> partial slot id (the task is a PIECE)
-    const uint2 *t_aux;      // [n_tasks]   pieces: {index into `split` of the piece's row, #pieces of that row}; else {0,0}
+    const uint32_t *t_dst;   // [n_tasks]   C row written by the task; MSB set -> partial slot id (the task is a PIECE), or, with
+                             //             kBundleFlag as well, a BUNDLE: low bits = its first entry in the chunk's part of bd_rows
+    const uint2 *t_aux;      // [n_tasks]   pieces: {index into `split` of the piece's row, #pieces of that row}; bundles: {first entry
+                             //             in bd_rows, steps}; else {0,0}
     const uint4 *chunk;      // [n_chunks] {first task, #tasks (<= 63), first record, end record}; one wave per chunk
     float *partial;          // [n_partials][k] partial sums of split rows
     const SplitRow *split;   // [n_split] {C row, first partial, #pieces}
@@ -35,6 +37,10 @@ struct PlanView {
                              // every XCD slice of the chunk table is walked group by group, all column tiles of a group back to back, so that
                              // a group's records are re-read while they are still in the Infinity Cache (1-D grid of n_workgroups x tiles)
     uint64_t *trace;         // flex_plan_measure_imbalance: 3 words per (k-tile, chunk-table entry); diagnostic -DFLEX_TRACE builds: 12 per wave; else nullptr
+    // Row bundles (plan_build.cpp, form_tasks): a task that holds up to S = 64 / G SHORT rows side by side, slot s of every step working
+    // on row s -- no cross-slot reduction, one 16-byte store per lane at the end.  nullptr when the plan has none.
+    const uint32_t *bd_rows; // per bundle S entries: C row of slot s | kBundleZero (the row holds no nonzero: zeros are stored), or kBundleNoRow
+    const uint2 *chunk_bd;   // [chunk-table entries] {first entry in bd_rows, entries (a multiple of S, <= kBundleRowsPerChunk)} of the chunk's bundles
 };
 
 
@@ -108,6 +114,11 @@ struct BlockView {
 };
 
 constexpr uint32_t kPartialFlag = 0x80000000u;
+constexpr uint32_t kBundleFlag = 0x40000000u;       // in t_dst, together with kPartialFlag: the task is a bundle of rows
+constexpr uint32_t kBundleZero = 0x80000000u;       // in bd_rows: store zeros (a row without nonzeros)
+constexpr uint32_t kBundleNoRow = 0xFFFFFFFFu;      // in bd_rows: the slot holds no row
+constexpr uint32_t kBundleRowsPerChunk = 128;       // a wave keeps its chunk's bd_rows entries in two registers per lane
+constexpr uint32_t kBundleMinSlots = 4;             // bundles only on tiles with at least this many record slots per step (G <= 16)
 constexpr int kWavesPerBlock = 4;  // 256-thread workgroups
 constexpr int kXcds = 8;           // MI355X: 8 XCDs, each with a private 4 MiB L2
 

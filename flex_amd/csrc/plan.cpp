@@ -57,6 +57,8 @@ void free_plan_device(flex_plan *p) {
     (void)hipFree(p->d_t_dst);
     (void)hipFree(p->d_t_aux);
     (void)hipFree(p->d_chunk);
+    (void)hipFree(p->d_bd_rows);
+    (void)hipFree(p->d_chunk_bd);
     (void)hipFree(p->d_partial);
     (void)hipFree(p->d_split);
     (void)hipFree(p->d_split_cnt);
@@ -340,6 +342,8 @@ int flex_plan_get_info(const flex_plan *p, flex_plan_info *o) {
     o->block_hot_cols = p->bk_hot_cols;
     o->block_panels = p->bk_panels;
     o->block_records = p->bk_records;
+    o->n_bundles = p->n_bundles;
+    o->bundle_rows = p->bundle_rows;
     return FLEX_OK;
 }
 

@@ -32,6 +32,10 @@ struct flex_plan {
     uint32_t *d_t_beg = nullptr, *d_t_dst = nullptr;
     uint2 *d_t_aux = nullptr;
     uint4 *d_chunk = nullptr;
+    uint32_t *d_bd_rows = nullptr;  // row bundles (internal.h, PlanView): nullptr when the plan has none
+    uint2 *d_chunk_bd = nullptr;
+    uint32_t n_bundles = 0, n_bd_rows = 0;  // bundles; entries of d_bd_rows (S per bundle)
+    int64_t bundle_rows = 0;                // rows that sit in bundles
     float *d_partial = nullptr;
     flex::SplitRow *d_split = nullptr;
     uint32_t *d_split_cnt = nullptr;
@@ -105,7 +109,7 @@ void free_plan_device(flex_plan *p);
 inline PlanView plan_view(const flex_plan *p, bool fused, uint64_t *trace) {
     return PlanView{p->d_rec, p->d_t_beg, p->d_t_dst, p->d_t_aux, p->d_chunk, p->d_partial, p->d_split, p->d_split_cnt,
                     fused ? 1u : 0u, p->n_slots, p->k, p->ldb, p->ldc,
-                    p->xcd_remap ? 1u : 0u, p->lds_extra, p->rec_nt ? 1u : 0u, p->tile_group, trace};
+                    p->xcd_remap ? 1u : 0u, p->lds_extra, p->rec_nt ? 1u : 0u, p->tile_group, trace, p->d_bd_rows, p->d_chunk_bd};
 }
 inline BlockView block_view(const flex_plan *p) {
     return BlockView{p->d_bk_hdr, p->d_bk_wstart, p->d_bk_cnt, p->d_bk_hcol, p->d_bk_brow, p->d_bk_link, p->d_bk_rec, static_cast<uint64_t>(std::max<int64_t>(p->bk_records, 1)),

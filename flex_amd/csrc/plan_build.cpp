@@ -41,6 +41,13 @@ struct Piece {
     uint32_t own_chunk;  // a slice of a run longer than one budget: a chunk of its own
 };
 constexpr uint32_t kFarPhase = 0xFFFFFFFEu;
+// What a task is made of: one piece, or a BUNDLE -- up to S short whole rows side by side, slot s of every step working on row s,
+// so that nothing is reduced across slots and a finished bundle is one 16-byte store per lane (spmm_kernels.hip, flush).
+struct TaskSpec {
+    uint32_t ref;    // a piece: its position in `emit`; a bundle: its first entry in `bundle_piece`
+    uint32_t rows;   // 0 = a piece; else the rows of the bundle (<= S)
+    uint32_t steps;  // bundle: the length of its longest row
+};
 constexpr uint32_t kMaxTasksPerWave = 63;  // the kernel hands descriptors out by lane (compute_chunk)
 
 class PlanBuilder {
@@ -89,6 +96,7 @@ class PlanBuilder {
         order_pieces();
         lap("emission order");
         number_split_rows();
+        form_tasks();
         if ((rc = pack_tasks_into_chunks())) return rc;
         fill_records();
         lap("records and tasks");
@@ -138,7 +146,16 @@ class PlanBuilder {
     const uint32_t *rcol = nullptr;  // where piece ranges point: A's arrays (1-D) or pcol/pval (2-D)
     const float *rval = nullptr;
     uint32_t slice_row[kXcds + 1] = {0};  // 2-D: schedule positions of the XCD slices
-    std::vector<uint32_t> emit;           // piece index of task t
+    std::vector<uint32_t> emit;           // pieces in emission order
+    // tasks
+    bool bundles_on = false;
+    uint32_t bundle_len = 0;              // rows of at most this many records are candidates for a bundle
+    std::vector<TaskSpec> tasks;
+    std::vector<uint32_t> bundle_piece;   // positions in `emit` of the rows of each bundle, longest first
+    std::vector<uint32_t> bd_rows;        // PlanView::bd_rows
+    std::vector<uint2> chunk_bd;          // per chunk {first entry in bd_rows, entries}
+    uint32_t n_bundles = 0;
+    int64_t bundle_rows = 0;
     // split rows
     std::vector<SplitRow> split;
     std::vector<uint32_t> row_sidx, row_first_partial;
@@ -433,6 +450,10 @@ class PlanBuilder {
         pshift = 0;
         while ((2ull << pshift) * tile_bytes <= panel_bytes) ++pshift;  // P = 2^pshift rows of B per panel
         seg_min = static_cast<uint32_t>(pick(tn.seg_min, 4));
+        // Row bundles (form_tasks): only on the tiles of 4 or more slots per step (the kernels of the wide tiles have no code for them),
+        // and not on 2-D plans (their tasks are runs of a row, not rows)
+        bundles_on = !two_d && S >= kBundleMinSlots && m > 0 && (tn.bundle == 1 || (tn.bundle != 2 && bundle_rule()));
+        bundle_len = static_cast<uint32_t>(pick(tn.bundle_len, 4L * S));
         far_window = two_d ? 0u : static_cast<uint32_t>(std::max(0, tn.far_first));  // (2-D pieces are cut by column panel already)
         p->tuning.far_first = static_cast<int32_t>(far_window);
         // what this plan was built with (flex_plan_get_tuning)
@@ -453,6 +474,9 @@ class PlanBuilder {
         u.host_threads = host_threads();
         u.cluster = tn.cluster;
     }
+
+    // The rule.  Measured on MI355X (profiles/r04_row_bundles.txt).
+    bool bundle_rule() const { return false; }
 
     // A run of `len` records as pieces: one, or (longer than a budget) several of about one budget.  The last piece to
     // arrive sums all of them with ONE wave, so a hub of 10^6 nonzeros cut into 10^4 budget-sized pieces spent 0.9 ms
@@ -621,19 +645,71 @@ class PlanBuilder {
         }
     }
 
-    // tasks (one per piece, in emission order) and the chunks (one wave each) they are packed into
+    // Which pieces become tasks of their own and which short rows share a bundle.  Candidates -- whole rows of at most `bundle_len`
+    // records -- are collected while the pieces go by (everything else keeps its place), 8 x S at a time, sorted by length and cut into
+    // groups of S: a group becomes a bundle when that takes fewer steps than its rows one after the other, a row by itself costing
+    // its steps (padded to S records each) plus a reduction across the slots, a store and the scalar bookkeeping of a task end
+    // (about 2.5 steps' worth of instructions on the G = 8 tile; a bundle's end about 1.5: one cross-lane read, one store).
+    void form_tasks() {
+        const uint32_t n_pieces = static_cast<uint32_t>(pieces.size());
+        tasks.clear();
+        tasks.reserve(n_pieces);
+        if (n_partials >= kBundleFlag) bundles_on = false;  // t_dst keeps partial-slot ids below the bundle flag
+        p->tuning.bundle = bundles_on ? 1 : 2;
+        p->tuning.bundle_len = bundles_on ? static_cast<int32_t>(bundle_len) : 0;
+        if (!bundles_on) {
+            for (uint32_t t = 0; t < n_pieces; ++t) tasks.push_back({t, 0u, 0u});
+            return;
+        }
+        constexpr uint32_t kRowEnd2 = 5, kBundleEnd2 = 3;  // in half steps
+        auto len_of = [&](uint32_t e) { return pieces[emit[e]].end - pieces[emit[e]].beg; };
+        std::vector<uint32_t> buf;
+        auto flush_buf = [&]() {
+            std::stable_sort(buf.begin(), buf.end(), [&](uint32_t a, uint32_t b) { return len_of(a) > len_of(b); });
+            for (size_t g = 0; g < buf.size(); g += S) {
+                const uint32_t n = static_cast<uint32_t>(std::min<size_t>(S, buf.size() - g));
+                const uint32_t steps = len_of(buf[g]);
+                uint32_t alone2 = 0;
+                for (uint32_t s = 0; s < n; ++s) alone2 += 2 * ((len_of(buf[g + s]) + S - 1) / S) + kRowEnd2;
+                if (n >= 2 && 2 * steps + kBundleEnd2 <= alone2) {
+                    tasks.push_back({static_cast<uint32_t>(bundle_piece.size()), n, steps});
+                    for (uint32_t s = 0; s < n; ++s) bundle_piece.push_back(buf[g + s]);
+                    ++n_bundles;
+                    bundle_rows += n;
+                } else {
+                    for (uint32_t s = 0; s < n; ++s) tasks.push_back({buf[g + s], 0u, 0u});
+                }
+            }
+            buf.clear();
+        };
+        for (uint32_t e = 0; e < n_pieces; ++e) {
+            const Piece &pc = pieces[emit[e]];
+            if (pc.own_chunk == 0 && pc.end - pc.beg <= bundle_len) {  // 1-D: a piece that is not a slice of a long row is a whole row
+                buf.push_back(e);
+                if (buf.size() == 8u * S) flush_buf();
+            } else {
+                tasks.push_back({e, 0u, 0u});
+            }
+        }
+        flush_buf();
+    }
+
+    // the chunks (one wave each) the tasks are packed into
     int pack_tasks_into_chunks() {
-        const uint32_t n_tasks = static_cast<uint32_t>(pieces.size());
+        const uint32_t n_tasks = static_cast<uint32_t>(tasks.size());
         t_beg.resize(static_cast<size_t>(n_tasks) + 1);
         t_dst.resize(n_tasks);
         t_aux.resize(n_tasks);
         uint64_t pos = 0;
-        uint32_t wave_cost = 0, cur_phase = 0, prev_own = 0;
+        uint32_t wave_cost = 0, cur_phase = 0, prev_own = 0, bd_first = 0;
         int cur_slice = 0;
         for (uint32_t t = 0; t < n_tasks; ++t) {
-            const Piece &pc = pieces[emit[t]];
-            const uint32_t len = pc.end - pc.beg;
-            bool fresh = w_task.empty() || wave_cost >= wave_nnz || t - w_task.back() >= kMaxTasksPerWave || pc.own_chunk || prev_own;
+            const TaskSpec &ts = tasks[t];
+            const Piece &pc = pieces[emit[ts.rows ? bundle_piece[ts.ref] : ts.ref]];  // a bundle: its first (longest) row
+            const uint32_t own = ts.rows ? 0u : pc.own_chunk;
+            const uint32_t len = ts.rows ? ts.steps * S : pc.end - pc.beg;
+            bool fresh = w_task.empty() || wave_cost >= wave_nnz || t - w_task.back() >= kMaxTasksPerWave || own || prev_own;
+            if (ts.rows && static_cast<uint32_t>(bd_rows.size()) - bd_first + S > kBundleRowsPerChunk) fresh = true;
             if (two_d) {
                 while (pc.spos >= slice_row[cur_slice + 1]) {  // first task of the next XCD slice
                     slice_chunk[++cur_slice] = static_cast<uint32_t>(w_task.size());
@@ -643,16 +719,33 @@ class PlanBuilder {
                 cur_phase = pc.phase;
             }
             if (fresh) {
+                if (!w_task.empty()) chunk_bd.push_back(make_uint2(bd_first, static_cast<uint32_t>(bd_rows.size()) - bd_first));
+                bd_first = static_cast<uint32_t>(bd_rows.size());
                 w_task.push_back(t);
                 wave_cost = 0;
             }
             wave_cost += len + row_cost;
-            prev_own = pc.own_chunk;
+            prev_own = own;
             t_beg[t] = static_cast<uint32_t>(pos);
-            pos += (len + S - 1) / S * S;  // padded to a whole number of steps
+            if (ts.rows) {
+                t_dst[t] = kPartialFlag | kBundleFlag | (static_cast<uint32_t>(bd_rows.size()) - bd_first);
+                t_aux[t] = make_uint2(static_cast<uint32_t>(bd_rows.size()), ts.steps);
+                for (uint32_t s = 0; s < S; ++s) {
+                    if (s < ts.rows) {
+                        const Piece &row = pieces[emit[bundle_piece[ts.ref + s]]];
+                        bd_rows.push_back(dst_of(sched[row.spos]) | (row.end == row.beg ? kBundleZero : 0u));
+                    } else {
+                        bd_rows.push_back(kBundleNoRow);
+                    }
+                }
+                pos += len;
+            } else {
+                pos += (len + S - 1) / S * S;  // padded to a whole number of steps
+            }
             if (pos >= (uint64_t(1) << 32)) return FLEX_ERR_UNSUPPORTED;  // 32-bit record offsets
         }
         t_beg[n_tasks] = static_cast<uint32_t>(pos);
+        if (!w_task.empty()) chunk_bd.push_back(make_uint2(bd_first, static_cast<uint32_t>(bd_rows.size()) - bd_first));
         w_task.push_back(n_tasks);
         if (m == 0) w_task.assign(1, 0u);
         if (two_d)
@@ -662,12 +755,61 @@ class PlanBuilder {
     }
 
     void fill_records() {
-        const uint32_t n_tasks = static_cast<uint32_t>(pieces.size());
+        const uint32_t n_tasks = static_cast<uint32_t>(tasks.size());
         const uint32_t row_bytes32 = static_cast<uint32_t>(p->ldb) * 4u;
         constexpr int64_t kTaskBlk = 4096;
+        auto record_of = [&](uint32_t e) {
+            uint32_t c = rcol[e];
+            if (col_map) c = static_cast<uint32_t>(col_map[c]);
+            uint32_t bits;
+            std::memcpy(&bits, &rval[e], 4);
+            return make_uint2(p->off32 ? c * row_bytes32 : c, bits);
+        };
+        // Padding behind the last real record `last` of a row: n_pad more records, `stride` apart.  B row = the last real one (always a
+        // valid address).  The padding does not carry value 0 -- 0 x inf would turn a row's +-inf into NaN (the oracle and the reference
+        // have no padding) -- but SHARES the last real record's value: v = v/2 + v/4 + ... + v/2^p + v/2^p, every part exact
+        // (power-of-two scaling), so a non-finite B value contributes what v itself would and a finite one the same product up to the
+        // last rounding.  Values too small to be halved p times without leaving the normal range keep the plain zero padding.
+        auto pad_row = [](uint2 *last, uint32_t n_pad, uint32_t stride) {
+            if (n_pad == 0) return;
+            const uint32_t ex = (last->y >> 23) & 0xFFu;  // biased exponent of v
+            if (ex > n_pad + 1 && ex < 0xFFu) {
+                float part;
+                std::memcpy(&part, &last->y, 4);
+                uint2 *q = last;  // the last real record takes v/2, the paddings v/4 ... v/2^p, v/2^p
+                for (uint32_t i = 0; i < n_pad; ++i, q += stride) {
+                    part *= 0.5f;
+                    uint32_t bits;
+                    std::memcpy(&bits, &part, 4);
+                    q->y = bits;
+                    q[stride] = make_uint2(q->x, bits);
+                }
+            } else {
+                for (uint32_t i = 1; i <= n_pad; ++i) last[static_cast<size_t>(i) * stride] = make_uint2(last->x, 0u);
+            }
+        };
         parallel_chunks((static_cast<int64_t>(n_tasks) + kTaskBlk - 1) / kTaskBlk, [&](int64_t b) {
             for (int64_t t = b * kTaskBlk; t < std::min<int64_t>(n_tasks, (b + 1) * kTaskBlk); ++t) {
-                const uint32_t pi = emit[t];
+                const TaskSpec &ts = tasks[t];
+                uint2 *const base = rec.data() + t_beg[t];
+                if (ts.rows) {
+                    // a bundle: record j of row s at [j][s]; slot 0 holds the longest row, so every step has a real record there
+                    // whose B row the slots without a row (and the rows without a nonzero) gather with value 0 -- they store
+                    // nothing (zeros), so what 0 x B makes of it is never seen
+                    for (uint32_t s = 0; s < S; ++s) {
+                        uint32_t len = 0;
+                        if (s < ts.rows) {
+                            const Piece &pc = pieces[emit[bundle_piece[ts.ref + s]]];
+                            len = pc.end - pc.beg;
+                            for (uint32_t j = 0; j < len; ++j) base[static_cast<size_t>(j) * S + s] = record_of(pc.beg + j);
+                        }
+                        if (len > 0) pad_row(base + static_cast<size_t>(len - 1) * S + s, ts.steps - len, S);
+                        else
+                            for (uint32_t j = 0; j < ts.steps; ++j) base[static_cast<size_t>(j) * S + s] = make_uint2(base[static_cast<size_t>(j) * S].x, 0u);
+                    }
+                    continue;
+                }
+                const uint32_t pi = emit[ts.ref];
                 const Piece &pc = pieces[pi];
                 const uint32_t i = pc.spos, r = sched[i];
                 const uint32_t np = row_first_piece[i + 1] - row_first_piece[i];
@@ -678,16 +820,9 @@ class PlanBuilder {
                     t_dst[t] = dst_of(r);
                     t_aux[t] = make_uint2(0u, 0u);
                 }
-                uint2 *o = rec.data() + t_beg[t];
-                auto emit_rec = [&](uint32_t e) {
-                    uint32_t c = rcol[e];
-                    if (col_map) c = static_cast<uint32_t>(col_map[c]);
-                    uint32_t bits;
-                    std::memcpy(&bits, &rval[e], 4);
-                    *o++ = make_uint2(p->off32 ? c * row_bytes32 : c, bits);
-                };
+                uint2 *o = base;
                 if (far_window == 0) {
-                    for (uint32_t e = pc.beg; e < pc.end; ++e) emit_rec(e);
+                    for (uint32_t e = pc.beg; e < pc.end; ++e) *o++ = record_of(e);
                 } else {
                     // FAR records first (tuning.far_first): a column whose vertex sits far from the row in the schedule is a likely L2
                     // miss, a near one a likely hit.  A wave's gathers return in issue order, so a group of U gathers waits for its
@@ -701,35 +836,13 @@ class PlanBuilder {
                         return (d < 0 ? -d : d) > static_cast<int64_t>(far_window);
                     };
                     for (uint32_t e = pc.beg; e < pc.end; ++e)
-                        if (is_far(e)) emit_rec(e);
+                        if (is_far(e)) *o++ = record_of(e);
                     for (uint32_t e = pc.beg; e < pc.end; ++e)
-                        if (!is_far(e)) emit_rec(e);
+                        if (!is_far(e)) *o++ = record_of(e);
                 }
-                // Pad to a whole number of steps: B row = the last real one (always a valid address).  The padding does not carry
-                // value 0 -- 0 x inf would turn a row's +-inf into NaN (the oracle and the reference have no padding) -- but SHARES
-                // the last real record's value: v = v/2 + v/4 + ... + v/2^p + v/2^p, every part exact (power-of-two scaling), so a
-                // non-finite B value contributes what v itself would and a finite one the same product up to the last rounding.
-                // Values too small to be halved p times without leaving the normal range keep the plain zero padding.
+                // pad to a whole number of steps
                 uint2 *const end = rec.data() + t_beg[t + 1];
-                const uint32_t n_pad = static_cast<uint32_t>(end - o);
-                if (n_pad > 0 && pc.end > pc.beg) {
-                    float v;
-                    std::memcpy(&v, &o[-1].y, 4);
-                    const uint32_t ex = (o[-1].y >> 23) & 0xFFu;  // biased exponent of v
-                    if (ex > n_pad + 1 && ex < 0xFFu) {
-                        float part = v;
-                        uint2 *q = o - 1;  // the last real record takes v/2, the paddings v/4 ... v/2^p, v/2^p
-                        for (uint32_t i = 0; i < n_pad; ++i, ++q) {
-                            part *= 0.5f;
-                            uint32_t bits;
-                            std::memcpy(&bits, &part, 4);
-                            q->y = bits;
-                            q[1] = make_uint2(q->x, bits);
-                        }
-                        o = end;
-                    }
-                }
-                for (; o < end; ++o) *o = make_uint2(o[-1].x, 0u);
+                if (o > base) pad_row(o - 1, static_cast<uint32_t>(end - o), 1u);
             }
         });
         pcol = std::vector<uint32_t>();
@@ -737,8 +850,11 @@ class PlanBuilder {
     }
 
     int upload_tasks() {
-        p->n_tasks = static_cast<uint32_t>(pieces.size());
+        p->n_tasks = static_cast<uint32_t>(tasks.size());
         p->n_records = rec.size();
+        p->n_bundles = n_bundles;
+        p->bundle_rows = bundle_rows;
+        p->n_bd_rows = static_cast<uint32_t>(bd_rows.size());
         p->c_rows = dst_map ? A->m : m;
         p->n_chunks = static_cast<uint32_t>(w_task.size() - 1);
         p->n_split = static_cast<uint32_t>(split.size());
@@ -750,6 +866,7 @@ class PlanBuilder {
         if ((rc = upload(&p->d_t_beg, t_beg, &p->device_bytes))) return rc;
         if ((rc = upload(&p->d_t_dst, t_dst, &p->device_bytes))) return rc;
         if ((rc = upload(&p->d_t_aux, t_aux, &p->device_bytes))) return rc;
+        if (n_bundles && (rc = upload(&p->d_bd_rows, bd_rows, &p->device_bytes))) return rc;
         p->n_tiles = static_cast<uint32_t>(tiles.boff.size() / 32);
         p->n_row_tiles = tiles.rt_ptr.empty() ? 0u : static_cast<uint32_t>(tiles.rt_ptr.size() - 1);
         p->tile_nnz = tiles.nnz;
@@ -774,6 +891,11 @@ class PlanBuilder {
             return make_uint4(w_task[c], w_task[c + 1] - w_task[c], t_beg[w_task[c]], t_beg[w_task[c + 1]]);
         };
         std::vector<uint4> chunk;
+        std::vector<uint2> cbd;  // the chunks' bundle tables, placed like the headers (left empty when the plan has no bundle)
+        auto place = [&](size_t at, uint32_t c) {
+            chunk[at] = header(c);
+            if (n_bundles) cbd[at] = chunk_bd[c];
+        };
         p->tuning.xcd_balance = tn.xcd_balance == 2 ? 2 : 1;
         if (xcd_dealt && !two_d && n_real >= 8u * kXcds * kWavesPerBlock) {
             // Stretches of the schedule dealt to the XCDs in turn: XCD x walks stretches x, x + 8, x + 16, ...  Each XCD still has a
@@ -789,10 +911,11 @@ class PlanBuilder {
             uint32_t longest = *std::max_element(len, len + kXcds);
             longest = (longest + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock;
             chunk.assign(static_cast<size_t>(longest) * kXcds, make_uint4(0u, 0u, 0u, 0u));
+            if (n_bundles) cbd.assign(chunk.size(), make_uint2(0u, 0u));
             uint32_t at[kXcds] = {};
             for (uint32_t s = 0; s < n_st; ++s) {
                 const uint32_t x = s % kXcds, c0 = s * per, c1 = std::min(n_real, c0 + per);
-                for (uint32_t c = c0; c < c1; ++c) chunk[static_cast<size_t>(x) * longest + at[x]++] = header(c);
+                for (uint32_t c = c0; c < c1; ++c) place(static_cast<size_t>(x) * longest + at[x]++, c);
             }
         } else if (two_d || (p->xcd_remap && n_real >= 8u * kXcds * kWavesPerBlock && tn.xcd_balance != 2)) {
             uint32_t cut[kXcds + 1];
@@ -823,16 +946,19 @@ class PlanBuilder {
             for (uint32_t x = 0; x < kXcds; ++x) longest = std::max(longest, cut[x + 1] - cut[x]);
             longest = (longest + kWavesPerBlock - 1) / kWavesPerBlock * kWavesPerBlock;
             chunk.assign(static_cast<size_t>(longest) * kXcds, make_uint4(0u, 0u, 0u, 0u));  // empty: no tasks, no records
+            if (n_bundles) cbd.assign(chunk.size(), make_uint2(0u, 0u));
             for (uint32_t x = 0; x < kXcds; ++x)
-                for (uint32_t c = cut[x]; c < cut[x + 1]; ++c) chunk[static_cast<size_t>(x) * longest + (c - cut[x])] = header(c);
+                for (uint32_t c = cut[x]; c < cut[x + 1]; ++c) place(static_cast<size_t>(x) * longest + (c - cut[x]), c);
         } else {
             chunk.resize(n_real);
-            for (uint32_t c = 0; c < n_real; ++c) chunk[c] = header(c);
+            if (n_bundles) cbd.resize(n_real);
+            for (uint32_t c = 0; c < n_real; ++c) place(c, c);
         }
         p->n_chunks = n_real;
         p->n_slots = static_cast<uint32_t>(chunk.size());
         int rc;
         if ((rc = upload(&p->d_chunk, chunk, &p->device_bytes))) return rc;
+        if (n_bundles && (rc = upload(&p->d_chunk_bd, cbd, &p->device_bytes))) return rc;
         if (flags & FLEX_PLAN_STATS) collect_stats(p, rec, chunk, split_nnz);
         // split-row workspace: the rows, one arrival counter per (row, column tile) -- zero between launches -- and the partial sums
         if ((rc = upload(&p->d_split, split, &p->device_bytes))) return rc;

@@ -159,29 +159,59 @@ int flex_plan_self_check(const flex_plan *p) try {
     std::vector<uint2> rec(p->n_records), t_aux(p->n_tasks);
     std::vector<uint32_t> t_beg(static_cast<size_t>(p->n_tasks) + 1), t_dst(p->n_tasks);
     std::vector<uint4> chunk(p->n_slots);
+    std::vector<uint2> chunk_bd(p->n_bundles ? p->n_slots : 0u);
+    std::vector<uint32_t> bd_rows(p->n_bd_rows);
     std::vector<SplitRow> split(p->n_split);
     auto down = [&](void *dst, const void *src, size_t bytes) { return bytes == 0 || hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess; };
     const bool ok_copy = down(rec.data(), p->d_rec, rec.size() * sizeof(uint2)) && down(t_beg.data(), p->d_t_beg, t_beg.size() * 4) &&
                          down(t_dst.data(), p->d_t_dst, t_dst.size() * 4) && down(chunk.data(), p->d_chunk, chunk.size() * sizeof(uint4)) &&
-                         down(split.data(), p->d_split, split.size() * sizeof(SplitRow)) && down(t_aux.data(), p->d_t_aux, t_aux.size() * sizeof(uint2));
+                         down(split.data(), p->d_split, split.size() * sizeof(SplitRow)) && down(t_aux.data(), p->d_t_aux, t_aux.size() * sizeof(uint2)) &&
+                         down(chunk_bd.data(), p->d_chunk_bd, chunk_bd.size() * sizeof(uint2)) && down(bd_rows.data(), p->d_bd_rows, bd_rows.size() * 4);
     if (cur != p->device) (void)hipSetDevice(cur);
     if (!ok_copy) return FLEX_ERR_HIP;
+    if ((p->n_bundles != 0) != (p->d_bd_rows != nullptr) || (p->n_bundles != 0) != (p->d_chunk_bd != nullptr)) return FLEX_ERR_FORMAT;
 
     // tasks tile the record stream
     if (t_beg[0] != 0 || t_beg[p->n_tasks] != p->n_records) return FLEX_ERR_FORMAT;
     for (uint32_t t = 0; t < p->n_tasks; ++t)
         if (t_beg[t] > t_beg[t + 1]) return FLEX_ERR_FORMAT;
     // chunks tile the tasks (in table order, skipping the empty padding entries), each within the kernel's limits
-    uint32_t next_task = 0, real = 0;
+    // ... and a chunk's bundles name consecutive groups of S entries of ITS part of bd_rows (what the wave holds in two registers per
+    // lane), each bundle's records are its steps x S, and the parts of the chunks tile bd_rows
+    const uint32_t S = 64u / static_cast<uint32_t>(p->lanes_per_nz);
+    uint32_t next_task = 0, real = 0, bundles = 0;
+    uint64_t bd_total = 0;
     std::vector<std::pair<uint32_t, uint32_t>> seen;  // real chunks as (first task, #tasks)
-    for (const uint4 &c : chunk) {
+    std::vector<std::pair<uint32_t, uint32_t>> bd_parts;
+    for (size_t ci = 0; ci < chunk.size(); ++ci) {
+        const uint4 &c = chunk[ci];
+        const uint2 cb = chunk_bd.empty() ? make_uint2(0u, 0u) : chunk_bd[ci];
         if (c.y == 0) {
-            if (c.x | c.z | c.w) return FLEX_ERR_FORMAT;
+            if (c.x | c.z | c.w | cb.x | cb.y) return FLEX_ERR_FORMAT;
             continue;
         }
         if (c.y > 63 || c.x + c.y > p->n_tasks || c.z != t_beg[c.x] || c.w != t_beg[c.x + c.y]) return FLEX_ERR_FORMAT;
+        if (cb.y > kBundleRowsPerChunk || cb.y % S != 0 || static_cast<uint64_t>(cb.x) + cb.y > bd_rows.size()) return FLEX_ERR_FORMAT;
+        uint32_t at = 0;
+        for (uint32_t t = c.x; t < c.x + c.y; ++t) {
+            if ((t_dst[t] & (kPartialFlag | kBundleFlag)) != (kPartialFlag | kBundleFlag)) continue;
+            if ((t_dst[t] & ~(kPartialFlag | kBundleFlag)) != at || t_aux[t].x != cb.x + at) return FLEX_ERR_FORMAT;
+            if (static_cast<uint64_t>(t_aux[t].y) * S != t_beg[t + 1] - t_beg[t]) return FLEX_ERR_FORMAT;
+            at += S;
+            ++bundles;
+        }
+        if (at != cb.y) return FLEX_ERR_FORMAT;
+        if (cb.y) bd_parts.emplace_back(cb.x, cb.y);
+        bd_total += cb.y;
         seen.emplace_back(c.x, c.y);
         ++real;
+    }
+    if (bundles != p->n_bundles || bd_total != bd_rows.size() || (S < kBundleMinSlots && bundles)) return FLEX_ERR_FORMAT;
+    std::sort(bd_parts.begin(), bd_parts.end());
+    uint32_t bd_next = 0;
+    for (const auto &part : bd_parts) {
+        if (part.first != bd_next) return FLEX_ERR_FORMAT;
+        bd_next += part.second;
     }
     if (real != p->n_chunks) return FLEX_ERR_FORMAT;
     std::sort(seen.begin(), seen.end());
@@ -200,9 +230,25 @@ int flex_plan_self_check(const flex_plan *p) try {
     // partial slot is written by exactly one task, and that task names its row and the row's piece count (t_aux:
     // what the arrival counter is compared with).  Pieces of a row need NOT be consecutive tasks (2-D schedules).
     std::vector<uint8_t> written(static_cast<size_t>(p->c_rows), 0), slot_taken(p->n_partials, 0);
+    int64_t in_bundles = 0;
     for (uint32_t t = 0; t < p->n_tasks; ++t) {
         const uint32_t d = t_dst[t];
-        if (d & kPartialFlag) {
+        if ((d & (kPartialFlag | kBundleFlag)) == (kPartialFlag | kBundleFlag)) {  // a bundle: every slot a row of its own, or none
+            int64_t rows_here = 0;
+            for (uint32_t s2 = 0; s2 < S; ++s2) {
+                const uint32_t row = bd_rows[t_aux[t].x + s2];
+                if (row == kBundleNoRow || (row & kBundleZero)) {  // nothing of what this slot sums is stored: it must sum zeros
+                    for (uint32_t j = 0; j < t_aux[t].y; ++j)
+                        if (rec[t_beg[t] + static_cast<size_t>(j) * S + s2].y != 0) return FLEX_ERR_FORMAT;
+                }
+                if (row == kBundleNoRow) continue;
+                const uint32_t dr = row & ~kBundleZero;
+                if (dr >= p->c_rows || written[dr]++) return FLEX_ERR_FORMAT;
+                ++rows_here;
+            }
+            if (rows_here == 0) return FLEX_ERR_FORMAT;
+            in_bundles += rows_here;
+        } else if (d & kPartialFlag) {
             const uint32_t ps = d & ~kPartialFlag;
             if (ps >= p->n_partials || slot_taken[ps]++) return FLEX_ERR_FORMAT;
             const uint2 a = t_aux[t];
@@ -213,6 +259,7 @@ int flex_plan_self_check(const flex_plan *p) try {
     }
     for (uint8_t w : slot_taken)
         if (w != 1) return FLEX_ERR_FORMAT;
+    if (in_bundles != p->bundle_rows) return FLEX_ERR_FORMAT;
     uint32_t first = 0;
     for (uint32_t i = 0; i < p->n_split; ++i) {
         const SplitRow &sr = split[i];

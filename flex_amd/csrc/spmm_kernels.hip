@@ -233,6 +233,10 @@ __device__ __forceinline__ void wait_loads(v4f (&v)[N]) {
 // 512 records (plan_build.cpp, read_knobs) -- one window per chunk there; measured with the budget
 template <int G>
 constexpr int kWindowRecs = G <= 8 ? 512 : 256;
+// Row bundles exist on the tiles with at least kBundleMinSlots slots per step (internal.h): the wide tiles have one or two slots --
+// little to gain -- and no register to spare for a chunk's bundle rows (72 VGPRs for seven waves per SIMD, see spmm_flat_kernel).
+template <int G>
+constexpr bool kTileHasBundles = 64 / G >= static_cast<int>(kBundleMinSlots);
 
 [[maybe_unused]] __device__ __forceinline__ uint32_t xcc_id() {
     uint32_t x;
@@ -303,7 +307,7 @@ __device__ __forceinline__ void stage_window(uint2 *my_lds, const uint2 *__restr
 // task descriptors (lane i: t_beg[t0+i], t_dst[t0+i]) are in registers.
 template <int G, bool OFF32, int U>
 __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint32_t my_beg, uint32_t my_dst, uint2 my_aux,
-                                              uint2 *my_lds, const char *__restrict__ Bb,
+                                              uint32_t my_bd0, uint32_t my_bd1, uint2 *my_lds, const char *__restrict__ Bb,
                                               float *__restrict__ C, int lane, int c0, bool col_ok, uint32_t tile, uint32_t ktiles
 #ifdef FLEX_TRACE
                                               , uint64_t *phase, uint64_t &last_
@@ -335,7 +339,22 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
     auto flush = [&](uint32_t pos) {
         do {
             const uint32_t dst = __builtin_amdgcn_readlane(my_dst, ti);
-            if (__builtin_expect((dst & kPartialFlag) != 0, 0)) {  // wave-uniform; the rare case on 1-D plans
+            if ((dst & (kPartialFlag | kBundleFlag)) == (kPartialFlag | kBundleFlag)) {  // wave-uniform
+                // a BUNDLE: slot s held row s of it all along -- nothing to reduce; every lane stores the 4 columns it owns of its
+                // slot's row (G lanes x 16 bytes: the row's whole column tile).  The chunk's rows came in with the descriptors
+                // (lane i: entries i and 64 + i of its part of bd_rows); the slot's lanes fetch theirs with one cross-lane read.
+                if constexpr (kTileHasBundles<G>) {
+                    const uint32_t first = dst & (kBundleRowsPerChunk - 1u);
+                    const uint32_t held = first < 64u ? my_bd0 : my_bd1;
+                    const uint32_t row = static_cast<uint32_t>(
+                        __builtin_amdgcn_ds_bpermute(static_cast<int>(((first & 63u) + slot) << 2), static_cast<int>(held)));
+                    if (col_ok && row != kBundleNoRow) {
+                        const bool none = (row & kBundleZero) != 0;  // a row without nonzeros: zeros, whatever its slot summed
+                        const v4f val = {none ? 0.f : acc.x, none ? 0.f : acc.y, none ? 0.f : acc.z, none ? 0.f : acc.w};
+                        __builtin_nontemporal_store(val, reinterpret_cast<v4f *>(C + static_cast<uint64_t>(row & ~kBundleZero) * ldc + c0));
+                    }
+                }
+            } else if (__builtin_expect((dst & kPartialFlag) != 0, 0)) {  // wave-uniform; the rare case on 1-D plans
                 const float4 r = reduce_full<G>(acc);
                 float *prow = p.partial + static_cast<uint64_t>(dst & ~kPartialFlag) * k;  // uniform
                 if (slot == 0 && col_ok) {
@@ -448,7 +467,7 @@ __device__ __forceinline__ void compute_chunk(const PlanView &p, uint4 hdr, uint
     // hand-offs on gfx950 / ROCm 7.2; measured, not an architectural guarantee, hence the 300-launch
     // test under uneven load, tests/test_gpu_spmm.py).  The workspace makes a plan non-reentrant: one
     // launch of a plan at a time (include/flex_spmm.h, flex_spmm).
-    const bool mine_partial = static_cast<uint32_t>(lane) < nt && (my_dst & kPartialFlag) != 0;
+    const bool mine_partial = static_cast<uint32_t>(lane) < nt && (my_dst & (kPartialFlag | kBundleFlag)) == kPartialFlag;
     if (p.fused_fixup && __builtin_amdgcn_ballot_w64(mine_partial) != 0) {  // wave-uniform
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint32_t arrived = 0;
@@ -551,7 +570,15 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(OFF32 
     const uint32_t my_beg = (static_cast<uint32_t>(lane) <= hdr.y) ? p.t_beg[hdr.x + lane] : 0u;
     const uint32_t my_dst = (static_cast<uint32_t>(lane) < hdr.y) ? p.t_dst[hdr.x + lane] : 0u;
     const uint2 my_aux = (static_cast<uint32_t>(lane) < hdr.y) ? p.t_aux[hdr.x + lane] : make_uint2(0u, 0u);
-    compute_chunk<G, OFF32, U>(p, hdr, my_beg, my_dst, my_aux, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok, tile, ktiles, phase, last_);
+    uint32_t my_bd0 = kBundleNoRow, my_bd1 = kBundleNoRow;
+    if constexpr (kTileHasBundles<G>) {
+        if (p.bd_rows != nullptr) {
+            const uint2 cb = p.chunk_bd[chunk];
+            if (static_cast<uint32_t>(lane) < cb.y) my_bd0 = p.bd_rows[cb.x + lane];
+            if (static_cast<uint32_t>(lane) + 64u < cb.y) my_bd1 = p.bd_rows[cb.x + 64u + lane];
+        }
+    }
+    compute_chunk<G, OFF32, U>(p, hdr, my_beg, my_dst, my_aux, my_bd0, my_bd1, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok, tile, ktiles, phase, last_);
     if (lane == 0 && p.trace != nullptr) {
         uint64_t *log = p.trace + static_cast<uint64_t>(chunk) * 12;
         log[0] = xcc_id();
@@ -570,13 +597,22 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(OFF32 
     // load per array and are handed out with v_readlane; the header carries the record range, so
     // the record fetch does not wait for them: header -> {descriptors, records} -> gathers.
     const uint4 hdr = p.chunk[chunk];
+    // the chunk's part of the bundle rows: fetched beside the header, handed out at the end of each bundle (compute_chunk, flush)
+    uint2 cb = make_uint2(0u, 0u);
+    if constexpr (kTileHasBundles<G>)
+        if (p.bd_rows != nullptr) cb = p.chunk_bd[chunk];  // uniform
     if (hdr.y == 0) return;  // an empty entry that pads this XCD's slice of the table (plan_build.cpp, build_chunk_table)
     const uint32_t my_beg = (static_cast<uint32_t>(lane) <= hdr.y) ? p.t_beg[hdr.x + lane] : 0u;
     const uint32_t my_dst = (static_cast<uint32_t>(lane) < hdr.y) ? p.t_dst[hdr.x + lane] : 0u;
     const uint2 my_aux = (static_cast<uint32_t>(lane) < hdr.y) ? p.t_aux[hdr.x + lane] : make_uint2(0u, 0u);  // read at chunk end only
+    uint32_t my_bd0 = kBundleNoRow, my_bd1 = kBundleNoRow;
+    if (kTileHasBundles<G> && cb.y != 0) {  // uniform
+        if (static_cast<uint32_t>(lane) < cb.y) my_bd0 = p.bd_rows[cb.x + lane];
+        if (static_cast<uint32_t>(lane) + 64u < cb.y) my_bd1 = p.bd_rows[cb.x + 64u + lane];
+    }
     uint64_t stamp_t0 = 0;
     if constexpr (STAMP) stamp_t0 = __builtin_amdgcn_s_memrealtime();
-    compute_chunk<G, OFF32, U>(p, hdr, my_beg, my_dst, my_aux, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok, tile, ktiles);
+    compute_chunk<G, OFF32, U>(p, hdr, my_beg, my_dst, my_aux, my_bd0, my_bd1, lds_rec[wib], reinterpret_cast<const char *>(B), C, lane, c0, col_ok, tile, ktiles);
     if constexpr (STAMP) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the wave's last stores have left
         const uint64_t stamp_t1 = __builtin_amdgcn_s_memrealtime();
@@ -596,7 +632,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(OFF32 
 // lane, lane+64, lane+128, lane+192 of the blockIdx.y-th 256-column tile.
 template <bool OFF32>
 __global__ __launch_bounds__(256) void spmm_generic_kernel(PlanView p, const float *__restrict__ B,
-                                                           float *__restrict__ C) {
+                                                           float *__restrict__ C, uint32_t slots_per_step) {
     const int lane = threadIdx.x & 63;
     const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t cpx = gridDim.x / kXcds;
@@ -610,6 +646,35 @@ __global__ __launch_bounds__(256) void spmm_generic_kernel(PlanView p, const flo
     for (uint32_t t = t0; t < t1; ++t) {
         const uint32_t zb = p.t_beg[t], ze = p.t_beg[t + 1];
         const uint32_t dst = p.t_dst[t];
+        if ((dst & (kPartialFlag | kBundleFlag)) == (kPartialFlag | kBundleFlag)) {  // a bundle: its rows one after the other
+            const uint2 a = p.t_aux[t];                                             // {first entry in bd_rows, steps}
+            const uint32_t slots = slots_per_step;                                  // record j of row s at zb + j * slots + s
+            for (uint32_t s = 0; s < slots; ++s) {
+                const uint32_t row = p.bd_rows[a.x + s];
+                if (row == kBundleNoRow) continue;
+                float acc[4] = {0.f, 0.f, 0.f, 0.f};
+                if ((row & kBundleZero) == 0) {
+                    for (uint32_t j = 0; j < a.y; ++j) {
+                        const uint2 r = rec[zb + j * slots + s];
+                        const float v = as_f32(r.y);
+                        const float *brow = OFF32 ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + r.x)
+                                                  : B + static_cast<uint64_t>(r.x) * p.ldb;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int c = cb + 64 * i;
+                            if (c < k) acc[i] = fmaf(v, brow[c], acc[i]);
+                        }
+                    }
+                }
+                float *orow = C + static_cast<uint64_t>(row & ~kBundleZero) * p.ldc;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = cb + 64 * i;
+                    if (c < k) orow[c] = acc[i];
+                }
+            }
+            continue;
+        }
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (uint32_t z = zb; z < ze; ++z) {
             const uint2 r = rec[z];
@@ -725,9 +790,9 @@ int launch_spmm(const PlanView &v, int lanes_per_nz, bool off32, bool vec4, cons
         nblk = (nblk + kXcds - 1) / kXcds * kXcds;
         const uint32_t ktiles = (v.k + 255) / 256;
         if (off32)
-            hipLaunchKernelGGL((spmm_generic_kernel<true>), dim3(nblk, ktiles), dim3(256), 0, s, v, dB, dC);
+            hipLaunchKernelGGL((spmm_generic_kernel<true>), dim3(nblk, ktiles), dim3(256), 0, s, v, dB, dC, 64u / static_cast<uint32_t>(lanes_per_nz));
         else
-            hipLaunchKernelGGL((spmm_generic_kernel<false>), dim3(nblk, ktiles), dim3(256), 0, s, v, dB, dC);
+            hipLaunchKernelGGL((spmm_generic_kernel<false>), dim3(nblk, ktiles), dim3(256), 0, s, v, dB, dC, 64u / static_cast<uint32_t>(lanes_per_nz));
         FLEX_HIP_TRY(hipGetLastError());
         return FLEX_OK;
     }

@@ -164,7 +164,12 @@ typedef struct flex_plan_tuning {
     int32_t far_first;       /* > 0: inside every task the records whose column lies more than this many schedule positions from the row come
                                 FIRST (a wave's gathers return in order: with the likely L2 misses issued together, only those groups of
                                 gathers wait for the fabric) (rule: see plan_build.cpp, fill_records) */
-    int32_t reserved[7];     /* zero */
+    int32_t bundle;          /* row bundles: tasks that hold up to 64 / lanes_per_nz SHORT rows side by side, one per record slot -- no
+                                cross-slot reduction and one store per lane at the end instead of a reduction and a store per row
+                                (≙ the reference's narrow kernel giving every thread its own row, flex.cu:81-118): 1 on, 2 off
+                                (rule: plan_build.cpp, form_tasks) */
+    int32_t bundle_len;      /* ... rows of at most this many nonzeros are candidates (4 x the slots of a step) */
+    int32_t reserved[5];     /* zero */
 } flex_plan_tuning;
 
 typedef struct flex_plan_desc {
@@ -206,7 +211,7 @@ int flex_plan_destroy(flex_plan *plan);
 typedef struct flex_plan_info {
     int32_t m, n, k, device;
     int64_t nnz;
-    int64_t n_tasks;      /* tasks: rows + pieces of split rows */
+    int64_t n_tasks;      /* tasks: rows + pieces of split rows + row bundles (the rows inside a bundle are not tasks of their own) */
     int64_t n_chunks;     /* schedule chunks (runs of tasks): one wave each, four to a workgroup */
     int64_t n_split_rows; /* rows long enough to be split over several waves */
     int64_t n_partials;   /* k-wide partial sums held in the workspace */
@@ -228,6 +233,9 @@ typedef struct flex_plan_info {
     int64_t block_hot_cols;   /* B rows staged, summed over blocks: block_hot_nnz / block_hot_cols = u, the reuse of a staged row */
     int64_t block_panels;     /* panels staged per column tile, summed over blocks */
     int64_t block_records;    /* records the hot kernel streams per 64-column tile: block_hot_nnz + padding */
+    /* row bundles (0 when the plan has none) */
+    int64_t n_bundles;        /* tasks that hold several short rows side by side */
+    int64_t bundle_rows;      /* rows inside them */
 } flex_plan_info;
 int flex_plan_get_info(const flex_plan *plan, flex_plan_info *out);
 

@@ -296,3 +296,65 @@ def test_hot_block_plans_are_partitions(sim, rounds, panel_rows, thr, cap):
         flex_amd.Plan(g, 128, order=flex_amd.FLEX_ORDER_CLUSTER, tuning=dict(knobs, host_threads=threads))
         images.append(sim.hostsim_upload_hash(1))
     assert images[0] == images[1]
+
+
+@pytest.mark.parametrize("k,lanes", [(8, 4), (16, 4), (32, 8), (64, 16), (128, 16), (128, 8), (30, 0)])
+def test_row_bundle_plans_are_partitions(sim, k, lanes):
+    """tuning.bundle = 1: short rows share tasks, one row per record slot (plan_build.cpp, form_tasks).  Every C row still has one
+    writer -- a task, a split row or ONE slot of one bundle -- a chunk's bundles name consecutive groups of its part of bd_rows, rows
+    without nonzeros and slots without a row sum zeros only (flex_plan_self_check); fewer tasks and fewer records than the plain plan
+    of the same matrix, the same nonzeros."""
+    a = random_csr(6000, 6000, 6, seed=21, long_rows={17: 5000, 4000: 900}, empty_frac=0.3)
+    knobs = {"bundle": 1}
+    if lanes:
+        knobs["lanes_per_nz"] = lanes
+    for order in (flex_amd.FLEX_ORDER_NATURAL, flex_amd.FLEX_ORDER_CLUSTER):
+        plain = flex_amd.Plan(a, k, order=order, tuning={**knobs, "bundle": 2})
+        p = flex_amd.Plan(a, k, order=order | flex_amd.FLEX_PLAN_STATS, tuning=knobs)
+        p.self_check()
+        info, t = p.info(), p.tuning()
+        slots = 64 // info["lanes_per_nz"]
+        assert t["bundle"] == 1 and t["bundle_len"] == 4 * slots and plain.tuning()["bundle"] == 2 and plain.info()["n_bundles"] == 0
+        assert info["n_bundles"] > 0 and info["bundle_rows"] >= 2 * info["n_bundles"] and info["bundle_rows"] <= slots * info["n_bundles"]
+        assert info["n_tasks"] < plain.info()["n_tasks"] and info["n_split_rows"] == plain.info()["n_split_rows"] > 0
+        assert info["n_records"] < plain.info()["n_records"] and info["n_records"] >= a.nnz
+    # mapped plans, row shards (an empty one too), padded storage; the candidate length is a knob
+    rank = flex_amd.order_cluster(a)
+    vo, ap = flex_amd.perm_csr(a, rank)
+    pm = flex_amd.Plan(ap, k, vo_mp=vo, tuning=knobs)
+    pm.self_check()
+    assert pm.info()["n_bundles"] > 0
+    if k % 4 == 0:
+        bounds = flex_amd.shard_rows(ap, k, 3)
+        for i in range(3):
+            ps = flex_amd.Plan(ap, k, rows=(bounds[i], bounds[i + 1]), col_map=vo, ldb=k + 8, ldc=k + 4, tuning=knobs)
+            ps.self_check()
+            assert ps.info()["n_bundles"] > 0
+    flex_amd.Plan(ap, k, rows=(5, 5), col_map=vo, tuning=knobs).self_check()
+    short = flex_amd.Plan(a, k, tuning={**knobs, "bundle_len": 2})
+    short.self_check()
+    assert 0 < short.info()["bundle_rows"] < p.info()["bundle_rows"] and short.tuning()["bundle_len"] == 2
+
+
+def test_row_bundles_of_rows_without_nonzeros_and_of_one_thread_or_five(sim):
+    # nothing but empty rows: bundles of zero steps; and the image does not depend on the host thread count
+    empty = flex_amd.HostCsr(np.zeros(1001, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.float32), n=1000)
+    pe = flex_amd.Plan(empty, 32, tuning={"bundle": 1})
+    pe.self_check()
+    assert pe.info()["n_bundles"] == 125 and pe.info()["bundle_rows"] == 1000 and pe.info()["n_records"] == 0
+    a = flex_amd.synth_graph(n=20000, nnz=20000 + 2 * 50000, community=100, p_in=0.55, p_near=0.25, seed=9)
+    sim.hostsim_upload_hash.restype = C.c_uint64
+    sim.hostsim_upload_hash.argtypes = [C.c_int]
+    imgs = []
+    for threads in (1, 5):
+        sim.hostsim_upload_hash(1)
+        p = flex_amd.Plan(a, 32, order=flex_amd.FLEX_ORDER_CLUSTER, tuning={"bundle": 1, "host_threads": threads})
+        image = sim.hostsim_upload_hash(1)
+        p.self_check()
+        imgs.append((p.info()["n_tasks"], p.info()["n_records"], p.info()["n_bundles"], p.info()["bundle_rows"], image))
+    assert imgs[0] == imgs[1]
+    # the 2-D schedule's tasks are runs of a row, not rows: no bundles there; nor on the wide tiles (one or two slots per step)
+    for knobs, k in (({"two_d": 1, "panel_kb": 32}, 32), ({"lanes_per_nz": 32}, 128), ({}, 256)):
+        p2 = flex_amd.Plan(a, k, tuning={"bundle": 1, **knobs})
+        p2.self_check()
+        assert p2.info()["n_bundles"] == 0 and p2.tuning()["bundle"] == 2 and p2.tuning()["bundle_len"] == 0

@@ -18,6 +18,7 @@ ENV_TO_KNOB = {
     "FLEX_CLUSTER_NO_REFINE": "cluster_no_refine", "FLEX_CLUSTER_STRETCH": "cluster_stretch", "FLEX_CLUSTER_SWEEPS": "cluster_sweeps",
     "FLEX_CLUSTER_STRIDE": "cluster_stride", "FLEX_BLOCKS": "blocks", "FLEX_BLOCK_ROUNDS": "block_rounds", "FLEX_BLOCK_PANEL_ROWS": "block_panel_rows",
     "FLEX_BLOCK_THR": "block_thr", "FLEX_BLOCK_CAP": "block_cap", "FLEX_TILE_GROUP": "tile_group", "FLEX_FAR_FIRST": "far_first",
+    "FLEX_BUNDLE": "bundle", "FLEX_BUNDLE_LEN": "bundle_len",
 }
 
 

@@ -20,7 +20,10 @@ budget_s = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
 rng = np.random.default_rng(seed)
 KNOBS = {
-    "FLEX_LANES": [None, None, "8", "16", "32", "64"],
+    "FLEX_LANES": [None, None, "4", "8", "16", "32", "64"],
+    # row bundles (short rows side by side, one per record slot): on for half of the cases, every candidate length
+    "FLEX_BUNDLE": [None, "1", "1", "2"],
+    "FLEX_BUNDLE_LEN": [None, None, "1", "9", "100"],
     "FLEX_WAVE_NNZ": [None, None, "32", "100", "512", "4000"],
     "FLEX_LONG_ROW": [None, None, "40", "300"],
     "FLEX_PIECE": [None, None, "16", "200"],
@@ -106,7 +109,7 @@ while time.time() < t_end:
                    sorted_cols=bool(rng.integers(0, 2)))
     if 64 <= m <= 4000 and n >= 64 and rng.integers(0, 2):
         a = with_blocks(a, rng)
-    k = int(rng.choice([1, 4, 5, 8, 32, 36, 64, 100, 128, 132, 256, 300]))
+    k = int(rng.choice([1, 4, 5, 8, 16, 32, 36, 64, 100, 128, 132, 256, 300]))
     strided = bool(rng.integers(0, 3) == 0)
     ldb = k + int(rng.choice([0, 4, 28])) if strided else k
     ldc = k + int(rng.choice([0, 4, 28])) if strided else k
