@@ -192,12 +192,14 @@ class PlanBuilder {
         // k <= 16: a B row is at most 64 bytes, and four lanes cover it -- 16 records per step instead of 8 with half of the lanes
         // gathering a column nobody stores (≙ the reference's narrow kernel, flex.cu:81-118: one thread per (row, column), 128 / k rows
         // per block).  Rows are padded to whole steps, so the narrow tile is the rule only where rows are long enough to fill them.
+        // (With row bundles -- form_tasks -- short rows sit side by side instead of being padded, and the narrow tile wins at every degree:
+        // epinions stand-in, degree 6.4, k=16: 12.2 us against 13.4 on the 8-lane tile, flickr shape 11.6 against 12.6.)
         const bool narrow_ok = k <= 16 && k % 4 == 0;
         if (force_G) {
             G = std::min(G, force_G);
         } else if (const int g_t = tn.lanes_per_nz; g_t == 8 || g_t == 16 || g_t == 32 || g_t == 64 || (g_t == 4 && narrow_ok)) {
             G = g_t == 4 ? 4 : std::min<int>(G, g_t);  // tuning experiments
-        } else if (narrow_ok && avg_deg >= 8.0) {
+        } else if (narrow_ok && (avg_deg >= 8.0 || tn.bundle == 1 || (tn.bundle != 2 && fills_the_chip()))) {
             G = 4;
         } else {
             G = std::min(G, 32);  // k = 256 as two 128-column tiles beats one 256-column tile on every shape measured
@@ -453,7 +455,7 @@ class PlanBuilder {
         // Row bundles (form_tasks): only on the tiles of 4 or more slots per step (the kernels of the wide tiles have no code for them),
         // and not on 2-D plans (their tasks are runs of a row, not rows)
         bundles_on = !two_d && S >= kBundleMinSlots && m > 0 && (tn.bundle == 1 || (tn.bundle != 2 && bundle_rule()));
-        bundle_len = static_cast<uint32_t>(pick(tn.bundle_len, 4L * S));
+        bundle_len = static_cast<uint32_t>(pick(tn.bundle_len, 16));
         far_window = two_d ? 0u : static_cast<uint32_t>(std::max(0, tn.far_first));  // (2-D pieces are cut by column panel already)
         p->tuning.far_first = static_cast<int32_t>(far_window);
         // what this plan was built with (flex_plan_get_tuning)
@@ -475,8 +477,23 @@ class PlanBuilder {
         u.cluster = tn.cluster;
     }
 
-    // The rule.  Measured on MI355X (profiles/r04_row_bundles.txt).
-    bool bundle_rule() const { return false; }
+    // Would the plan, cut the usual way, hold at least one chunk for every wave slot of the card (256 CUs x 32)?  Below that a launch is
+    // bound by the latency of ONE wave's chain -- header, descriptors, records, gathers, store -- and not by instruction or memory
+    // throughput, and what shortens the chain is MORE lanes per row, not fewer.
+    bool fills_the_chip() const {
+        const double budget = std::clamp(16.0 * avg_deg, 128.0, 512.0);
+        return (static_cast<double>(slice_nnz()) + 16.0 * m) / budget >= 8192.0;
+    }
+    // The rule for row bundles, measured on MI355X (profiles/r04_row_bundles.txt; kernel time per launch, bundles off -> on):
+    //   k=32 (8 slots per step): epinions stand-in (131 828 rows of average degree 6.4) 19.3 -> 14.8 us, flickr shape (degree 11)
+    //   16.1 -> 12.9, yelp shape (degree 19) 130.5 -> 120.2, reddit shape (degree 50, few short rows) 161.4 -> 160.9;
+    //   k=64 (4 slots): 27.3 -> 25.2, 24.3 -> 21.8;  k=16 (16 slots): 18.1 -> 12.2, 14.8 -> 11.6;
+    //   wave instructions per 64 multiply-adds on the epinions stand-in at k=32: 10.4 VALU + 10.5 SALU -> 3.9 + 3.7.
+    // Graphs that do not fill the chip LOSE (pubmed.csv k=32 5.14 -> 5.37 us, wiki-Vote shape k=16 5.5 -> 7.3, ppi shape 8.2 -> 8.4):
+    // a bundle walks its rows' records one step after the other where the plain form spreads a row over the slots of one step,
+    // and a launch that short is the length of one wave's chain.  Candidate length: 12-16 records is the optimum on all three tiles
+    // (24-32: +2-7 %, longer chains and more padding inside a bundle); hence 16.
+    bool bundle_rule() const { return fills_the_chip(); }
 
     // A run of `len` records as pieces: one, or (longer than a budget) several of about one budget.  The last piece to
     // arrive sums all of them with ONE wave, so a hub of 10^6 nonzeros cut into 10^4 budget-sized pieces spent 0.9 ms

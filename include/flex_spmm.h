@@ -124,7 +124,7 @@ typedef struct flex_cluster_tuning { /* flex_order_cluster_ex / FLEX_ORDER_CLUST
     int32_t stride;    /* largest sampling stride of a long row (4) */
 } flex_cluster_tuning;
 typedef struct flex_plan_tuning {
-    int32_t lanes_per_nz;    /* G = 8 / 16 / 32 / 64 lanes per record (column tile of 4G columns), capped by k */
+    int32_t lanes_per_nz;    /* G = 4 (k <= 16 only) / 8 / 16 / 32 / 64 lanes per record (column tile of 4G columns), capped by k */
     int32_t chunk_records;   /* chunk budget: records per wave */
     int32_t long_row;        /* rows longer than this are cut into pieces (chunk_records) */
     int32_t piece_records;   /* ... of about this many records (chunk_records) */
@@ -167,8 +167,9 @@ typedef struct flex_plan_tuning {
     int32_t bundle;          /* row bundles: tasks that hold up to 64 / lanes_per_nz SHORT rows side by side, one per record slot -- no
                                 cross-slot reduction and one store per lane at the end instead of a reduction and a store per row
                                 (≙ the reference's narrow kernel giving every thread its own row, flex.cu:81-118): 1 on, 2 off
-                                (rule: plan_build.cpp, form_tasks) */
-    int32_t bundle_len;      /* ... rows of at most this many nonzeros are candidates (4 x the slots of a step) */
+                                (rule: on the tiles of 4 or more slots per step -- k <= 64, or lanes_per_nz <= 16 -- when the plan holds a
+                                chunk for every wave slot of the card; plan_build.cpp, bundle_rule) */
+    int32_t bundle_len;      /* ... rows of at most this many nonzeros are candidates (16) */
     int32_t reserved[5];     /* zero */
 } flex_plan_tuning;
 

@@ -314,7 +314,7 @@ def test_row_bundle_plans_are_partitions(sim, k, lanes):
         p.self_check()
         info, t = p.info(), p.tuning()
         slots = 64 // info["lanes_per_nz"]
-        assert t["bundle"] == 1 and t["bundle_len"] == 4 * slots and plain.tuning()["bundle"] == 2 and plain.info()["n_bundles"] == 0
+        assert t["bundle"] == 1 and t["bundle_len"] == 16 and plain.tuning()["bundle"] == 2 and plain.info()["n_bundles"] == 0
         assert info["n_bundles"] > 0 and info["bundle_rows"] >= 2 * info["n_bundles"] and info["bundle_rows"] <= slots * info["n_bundles"]
         assert info["n_tasks"] < plain.info()["n_tasks"] and info["n_split_rows"] == plain.info()["n_split_rows"] > 0
         assert info["n_records"] < plain.info()["n_records"] and info["n_records"] >= a.nnz
@@ -358,3 +358,22 @@ def test_row_bundles_of_rows_without_nonzeros_and_of_one_thread_or_five(sim):
         p2 = flex_amd.Plan(a, k, tuning={"bundle": 1, **knobs})
         p2.self_check()
         assert p2.info()["n_bundles"] == 0 and p2.tuning()["bundle"] == 2 and p2.tuning()["bundle_len"] == 0
+
+
+def test_row_bundles_by_rule_only_where_the_plan_fills_the_chip(sim):
+    """No knob set: the flickr shape (89 250 rows, degree 11: ~13 000 chunks) gets bundles on the tiles that have them (k <= 64) and the
+    narrow tile at k = 16 although its degree is below 8; pubmed.csv (19 717 rows, ~5 500 chunks) does not -- a launch that short is
+    one wave's chain long, and a bundle's chain is the longer one (plan_build.cpp, bundle_rule)."""
+    fl = flex_amd.synth_graph("flickr")
+    pm = flex_amd.csv_load(os.path.join(os.path.dirname(__file__), "golden", "pubmed.csv"))
+    for k, lanes, on in ((16, 4, True), (32, 8, True), (64, 16, True), (128, 32, False)):
+        p = flex_amd.Plan(fl, k, order=flex_amd.FLEX_ORDER_CLUSTER)
+        p.self_check()
+        i, t = p.info(), p.tuning()
+        assert i["lanes_per_nz"] == lanes and (i["n_bundles"] > 1000) == on and t["bundle"] == (1 if on else 2), (k, i, t)
+        assert t["bundle_len"] == (16 if on else 0)
+    for k, lanes in ((16, 8), (32, 8), (64, 16)):
+        p = flex_amd.Plan(pm, k)
+        assert p.info()["n_bundles"] == 0 and p.tuning()["bundle"] == 2 and p.info()["lanes_per_nz"] == lanes
+    off = flex_amd.Plan(fl, 32, tuning={"bundle": 2})
+    assert off.info()["n_bundles"] == 0 and off.info()["n_tasks"] > 4 * flex_amd.Plan(fl, 32).info()["n_tasks"]
