@@ -17,19 +17,22 @@
 //    columns of C, so one wave-instruction gathers 64/G different B rows with
 //    16-byte loads (k=128: two 512-B rows = 1 KiB per global_load_dwordx4;
 //    k=32: eight 128-B rows).  The S = 64/G slots of a wave walk the SAME row
-//    and are combined by a log2(S)-step xor-shuffle at row end.
+//    and are combined by a log2(S)-step xor-shuffle at row end -- or, for SHORT rows on
+//    the tiles of four or more slots, S DIFFERENT rows of one bundle (a task that holds
+//    a row per slot): nothing to combine, one 16-byte store per lane at the bundle's end
+//    (plan_build.cpp form_tasks; ≙ the reference's narrow kernel, flex.cu:81-118).
 //  * Rows of GNN graphs are short (median degree < 10), so the wave treats ALL
 //    records of a chunk as one stream of steps (S records per step; the planner
-//    pads every row to a multiple of S with zero-valued records): the records are
+//    pads every row to a multiple of S with records that share its last value): the records are
 //    fetched once, coalesced, into a wave-private LDS slice, then blocks of U
 //    gathers are issued back to back regardless of row boundaries, and a
 //    wave-uniform scalar check after each step flushes the accumulator when a row
 //    ends.  No barriers: LDS slices are private to a wave.
 //  * C is written once with non-temporal 16-byte stores; rows cut into several
 //    pieces go to k-wide partial slots instead and are summed in piece order -- by
-//    spmm_fixup_kernel after this launch (the default since ABI 3: it needs nothing
-//    beyond stream order) or, on request (flex_plan_tuning.split_rows = 1), by
-//    whichever piece finishes last inside the same launch.  Deterministic either way;
+//    spmm_fixup_kernel after this launch (large launches: it needs nothing beyond
+//    stream order) or by whichever piece finishes last inside the same launch (small
+//    ones, where a second kernel boundary would show; flex_plan_tuning.split_rows forces).  Deterministic either way;
 //    the reference uses atomicAdd for its split rows, mat.cu:816-824.
 #include "internal.h"
 
