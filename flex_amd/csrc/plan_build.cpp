@@ -205,6 +205,11 @@ class PlanBuilder {
             G = std::min(G, 32);  // k = 256 as two 128-column tiles beats one 256-column tile on every shape measured
             if (avg_deg >= 24.0) G = std::min(G, 16);
             if (avg_deg >= 128.0) G = std::min(G, 8);
+            // With row bundles the 16-lane tile is the better one at LOW degree too: its short rows cost no more instructions than on
+            // the wide tile, and two passes over half-rows of B keep more of them in the L2s (k=128, 32-lane tile without bundles ->
+            // 16-lane tile with: epinions stand-in 47.9 -> 46.1 us on 316 -> 300 MB, yelp shape 533 -> 519 us on 3.59 -> 3.22 GB,
+            // flickr shape 38.2 -> 38.1; profiles/r04_row_bundles.txt).  The 8-lane tile loses again (48.3 / 560 / 38.6).
+            if (tn.bundle == 1 || (tn.bundle != 2 && fills_the_chip())) G = std::min(G, 16);
         }
         S = 64u / static_cast<uint32_t>(G);
         p->lanes_per_nz = G;

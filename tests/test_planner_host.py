@@ -354,26 +354,27 @@ def test_row_bundles_of_rows_without_nonzeros_and_of_one_thread_or_five(sim):
         imgs.append((p.info()["n_tasks"], p.info()["n_records"], p.info()["n_bundles"], p.info()["bundle_rows"], image))
     assert imgs[0] == imgs[1]
     # the 2-D schedule's tasks are runs of a row, not rows: no bundles there; nor on the wide tiles (one or two slots per step)
-    for knobs, k in (({"two_d": 1, "panel_kb": 32}, 32), ({"lanes_per_nz": 32}, 128), ({}, 256)):
+    for knobs, k in (({"two_d": 1, "panel_kb": 32}, 32), ({"lanes_per_nz": 32}, 128), ({"lanes_per_nz": 64}, 256)):
         p2 = flex_amd.Plan(a, k, tuning={"bundle": 1, **knobs})
         p2.self_check()
         assert p2.info()["n_bundles"] == 0 and p2.tuning()["bundle"] == 2 and p2.tuning()["bundle_len"] == 0
 
 
 def test_row_bundles_by_rule_only_where_the_plan_fills_the_chip(sim):
-    """No knob set: the flickr shape (89 250 rows, degree 11: ~13 000 chunks) gets bundles on the tiles that have them (k <= 64) and the
-    narrow tile at k = 16 although its degree is below 8; pubmed.csv (19 717 rows, ~5 500 chunks) does not -- a launch that short is
+    """No knob set: the flickr shape (89 250 rows, degree 11: ~13 000 chunks) gets bundles, on the 16-lane tile from k = 64 up (with
+    bundles it beats the wide tile at low degree too) and on the narrow tile at k = 16 although its degree is below 8; pubmed.csv (19 717 rows, ~5 500 chunks) does not -- a launch that short is
     one wave's chain long, and a bundle's chain is the longer one (plan_build.cpp, bundle_rule)."""
     fl = flex_amd.synth_graph("flickr")
     pm = flex_amd.csv_load(os.path.join(os.path.dirname(__file__), "golden", "pubmed.csv"))
-    for k, lanes, on in ((16, 4, True), (32, 8, True), (64, 16, True), (128, 32, False)):
+    for k, lanes, on in ((16, 4, True), (32, 8, True), (64, 16, True), (128, 16, True), (256, 16, True)):
         p = flex_amd.Plan(fl, k, order=flex_amd.FLEX_ORDER_CLUSTER)
         p.self_check()
         i, t = p.info(), p.tuning()
         assert i["lanes_per_nz"] == lanes and (i["n_bundles"] > 1000) == on and t["bundle"] == (1 if on else 2), (k, i, t)
         assert t["bundle_len"] == (16 if on else 0)
-    for k, lanes in ((16, 8), (32, 8), (64, 16)):
+    for k, lanes in ((16, 8), (32, 8), (64, 16), (128, 32)):
         p = flex_amd.Plan(pm, k)
         assert p.info()["n_bundles"] == 0 and p.tuning()["bundle"] == 2 and p.info()["lanes_per_nz"] == lanes
+    assert flex_amd.Plan(fl, 128, tuning={"bundle": 2}).info()["lanes_per_nz"] == 32  # without bundles the wide tile stays the rule
     off = flex_amd.Plan(fl, 32, tuning={"bundle": 2})
     assert off.info()["n_bundles"] == 0 and off.info()["n_tasks"] > 4 * flex_amd.Plan(fl, 32).info()["n_tasks"]
