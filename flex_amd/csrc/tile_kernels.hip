@@ -25,21 +25,28 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef FLEX_TILE_WAVES
+#define FLEX_TILE_WAVES 3  // waves per SIMD the register allocator aims for (two whole tiles of operands are live in the loop)
+#endif
 constexpr int kTileNT = 2;  // 32-column output tiles per wave: 64 columns of C per wave, grid.y = ceil(k / 64)
 
-// One wave = one row tile x 64 columns of C.  The loop is software-pipelined by hand: the sixteen B values of the next
-// k-group (four k-steps x kTileNT output tiles) and the next tile's A block and column offsets are in flight while the
-// MFMAs of the current group issue -- a wave otherwise spends six dependent memory round trips per tile (measured: 12 500
-// tiles took 220 us; the matrix cores need 21).
+// One wave = one row tile x 64 columns of C.  The loop is software-pipelined by hand, a whole tile deep: the 32 B values per lane
+// and the A block of the NEXT tile, and the column offsets of the tile after it, are in flight while the MFMAs of the current tile
+// issue (the matrix cores need 21 us for the 12 500-tile probe, the fabric 69 us for its 415 MB).
 template <bool OFF32>
-__global__ __launch_bounds__(256) void spmm_tile_kernel(TileView tv, const float *__restrict__ B, float *__restrict__ C, int k,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(FLEX_TILE_WAVES))) void spmm_tile_kernel(TileView tv, const float *__restrict__ B, float *__restrict__ C, int k,
                                                         int ldb, int ldc) {
     constexpr int NT = kTileNT;
     const int lane = threadIdx.x & 63;
-    const uint32_t rt = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // 64-column groups of C: for 1, 2 or 4 of them (k <= 256) the waves of a row tile's groups sit side by side in one workgroup
+    // (1-D grid), so that the A blocks they all read come from HBM once; otherwise the group is the slow grid dimension.
+    const uint32_t wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t groups = (static_cast<uint32_t>(k) + 32 * NT - 1) / (32 * NT);
+    const bool side_by_side = gridDim.y == 1;
+    const uint32_t rt = side_by_side ? wid / groups : wid;
     if (rt >= tv.n_row_tiles) return;
     const int half = lane >> 5, j = lane & 31;
-    const int n_base = blockIdx.y * (32 * NT);
+    const int n_base = static_cast<int>(side_by_side ? wid % groups : blockIdx.y) * (32 * NT);
     const uint32_t t0 = tv.rt_ptr[rt], t1 = tv.rt_ptr[rt + 1];
     const uint32_t row_l = tv.rt_rows[static_cast<uint64_t>(rt) * 32 + j];  // used by the epilogue only: issued early
     f32x16 acc[NT];
@@ -59,32 +66,44 @@ __global__ __launch_bounds__(256) void spmm_tile_kernel(TileView tv, const float
 #pragma unroll
         for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const f32x4 *>(tv.a + (static_cast<uint64_t>(t) * 4 + q) * 256 + lane * 4);
     };
+    // OFF32: SGPR base + one 32-bit VGPR offset per load (a 64-bit address per load would hold two registers each while 32 loads are in flight)
+    const char *const Bb = reinterpret_cast<const char *>(B);
+    uint32_t loff[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) loff[nt] = static_cast<uint32_t>(col[nt]) * 4u;
     auto load_b = [&](uint32_t boff_l, int q, float (&b)[4][NT]) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const uint32_t off = __shfl(boff_l, 2 * (4 * q + e) + half);
-            const float *brow = OFF32 ? reinterpret_cast<const float *>(reinterpret_cast<const char *>(B) + off)
-                                      : B + static_cast<uint64_t>(off) * ldb;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[e][nt] = brow[col[nt]];
+            for (int nt = 0; nt < NT; ++nt) {
+                if constexpr (OFF32) b[e][nt] = *reinterpret_cast<const float *>(Bb + static_cast<uint32_t>(off + loff[nt]));
+                else b[e][nt] = (B + static_cast<uint64_t>(off) * ldb)[col[nt]];
+            }
         }
     };
     uint32_t boff_cur = tv.boff[static_cast<uint64_t>(t0) * 32 + j];
+    uint32_t boff_nxt = tv.boff[static_cast<uint64_t>(min(t0 + 1, t1 - 1)) * 32 + j];
     f32x4 a_cur[4];
     load_a(t0, a_cur);
-    float bq[4][NT];
-    load_b(boff_cur, 0, bq);
+    float bq[4][4][NT];  // the B operands of one whole tile: [k-group][k-step][output tile]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) load_b(boff_cur, q, bq[q]);
     for (uint32_t t = t0; t < t1; ++t) {
         bool any_bad = false;  // a non-finite B value among this tile's operands (per lane)
-        const uint32_t tn = min(t + 1, t1 - 1);  // the last tile prefetches itself: harmless, keeps every load unconditional
-        const uint32_t boff_nxt = tv.boff[static_cast<uint64_t>(tn) * 32 + j];
+        // The NEXT tile's operands -- its 32 B values per lane and its A block -- and the column offsets of the tile AFTER it (the B
+        // addresses of the next round of loads) are all in flight before this tile's first MFMA: a tile is 2 048 MFMA cycles (~1 us)
+        // per wave, a load under traffic comes back in 1-3 us, and with one k-group of look-ahead (rounds 2-3) the wave stalled in
+        // every k-group (118 us for the 12 500-tile probe's 415 MB: 3.5 TB/s).  The last tiles prefetch the last tile again:
+        // harmless, keeps every load unconditional.
+        const uint32_t boff_nn = tv.boff[static_cast<uint64_t>(min(t + 2, t1 - 1)) * 32 + j];
         f32x4 a_nxt[4];
-        load_a(tn, a_nxt);
+        load_a(min(t + 1, t1 - 1), a_nxt);
+        float bn[4][4][NT];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) load_b(boff_nxt, q, bn[q]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float bn[4][NT];
-            if (q < 3) load_b(boff_cur, q + 1, bn);
-            else load_b(boff_nxt, 0, bn);
             // A tile is stored dense: its absent cells are zeros of the A operand, and 0 x inf = NaN would reach rows that do not
             // reference that B row (the vector kernel, the oracle and the reference never touch it).  Non-finite B values therefore
             // enter the MFMA as 0; their exact contribution -- to the rows whose cell is present, explicit zeros included -- is added
@@ -93,15 +112,11 @@ __global__ __launch_bounds__(256) void spmm_tile_kernel(TileView tv, const float
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const float bv = col_ok[nt] ? bq[e][nt] : 0.f;
+                    const float bv = col_ok[nt] ? bq[q][e][nt] : 0.f;
                     const bool bad = (__float_as_uint(bv) & 0x7F800000u) == 0x7F800000u;
                     any_bad |= bad;
                     acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[q][e], bad ? 0.f : bv, acc[nt], 0, 0, 0);
                 }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bq[e][nt] = bn[e][nt];
         }
         if (__builtin_amdgcn_ballot_w64(any_bad) != 0) {  // wave-uniform, rare: the exact share of this tile's non-finite B values
             const uint32_t mask_l = tv.mask[static_cast<uint64_t>(t) * 32 + j];  // lane j holds row j's cell mask
@@ -125,35 +140,46 @@ __global__ __launch_bounds__(256) void spmm_tile_kernel(TileView tv, const float
             }
         }
         boff_cur = boff_nxt;
+        boff_nxt = boff_nn;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a_cur[q] = a_nxt[q];
-    }
-    // C[rows of this row tile, :] += acc   (the vector kernel wrote those rows earlier on this stream).  All sixteen
-    // loads of an output tile go out before the first add: a load -> add -> store chain per element is sixty-four
-    // dependent round trips (the compiler cannot move a load of one C row above the store to another).
+        for (int q = 0; q < 4; ++q) {
+            a_cur[q] = a_nxt[q];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        float *ptr[16];
-        float old[16];
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const uint32_t dst = __shfl(row_l, (reg & 3) + 8 * (reg >> 2) + 4 * half);
-            // a row tile that hangs over the end of the schedule: point at a row that exists, never store
-            ptr[reg] = dst == 0xFFFFFFFFu ? nullptr : C + static_cast<uint64_t>(dst) * ldc + col[nt];
+                for (int nt = 0; nt < NT; ++nt) bq[q][e][nt] = bn[q][e][nt];
         }
+    }
+    // C[rows of this row tile, :] += acc   (the vector kernel wrote those rows earlier on this stream).  All loads of BOTH
+    // output tiles go out before the first add: a load -> add -> store chain per element is sixty-four dependent round trips
+    // (the compiler cannot move a load of one C row above the store to another), and one chain per output tile is still two.
+    float *base[16];  // column n_base + j of each of the sixteen C rows this lane holds; output tile nt sits 32 columns further
+    float old[NT][16];
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) old[reg] = (ptr[reg] && col_ok[nt]) ? *ptr[reg] : 0.f;
+    for (int reg = 0; reg < 16; ++reg) {
+        const uint32_t dst = __shfl(row_l, (reg & 3) + 8 * (reg >> 2) + 4 * half);
+        // a row tile that hangs over the end of the schedule names no row there: never loaded, never stored
+        base[reg] = dst == 0xFFFFFFFFu ? nullptr : C + static_cast<uint64_t>(dst) * ldc + n_base + j;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) old[nt][reg] = (base[reg] && col_ok[nt]) ? base[reg][32 * nt] : 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
-            if (ptr[reg] && col_ok[nt]) *ptr[reg] = old[reg] + acc[nt][reg];
-    }
+            if (base[reg] && col_ok[nt]) base[reg][32 * nt] = old[nt][reg] + acc[nt][reg];
 }
 
 }  // namespace
 
 int launch_tiles(const TileView &tv, bool off32, const float *dB, float *dC, int k, int ldb, int ldc, hipStream_t s) {
     if (tv.n_row_tiles == 0) return FLEX_OK;
-    const dim3 grid((tv.n_row_tiles + 3) / 4, (k + 32 * kTileNT - 1) / (32 * kTileNT)), block(256);
+    const uint32_t groups = (static_cast<uint32_t>(k) + 32 * kTileNT - 1) / (32 * kTileNT);
+    const bool side_by_side = groups == 1 || groups == 2 || groups == 4;  // a workgroup's 4 waves hold whole row tiles
+    const dim3 grid = side_by_side ? dim3((tv.n_row_tiles * groups + 3) / 4, 1) : dim3((tv.n_row_tiles + 3) / 4, groups);
+    const dim3 block(256);
     if (off32)
         hipLaunchKernelGGL(spmm_tile_kernel<true>, grid, block, 0, s, tv, dB, dC, k, ldb, ldc);
     else

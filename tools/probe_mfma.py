@@ -51,13 +51,18 @@ def timed(a, B, C, env):
     return e0.elapsed_time(e1) * 1e3 / 20, info, out
 
 
-for block, fill, noise in ((64, 0.9, 8), (64, 0.6, 8), (64, 0.3, 8), (64, 0.15, 8), (128, 0.3, 8), (32, 0.5, 16)):
+# PROBE_CASES="64:0.3:8,..." restricts the cases (block:fill:noise), PROBE_THR="10" the routing thresholds (for profiler passes)
+CASES = [(64, 0.9, 8), (64, 0.6, 8), (64, 0.3, 8), (64, 0.15, 8), (128, 0.3, 8), (32, 0.5, 16)]
+if os.environ.get("PROBE_CASES"):
+    CASES = [(int(c.split(":")[0]), float(c.split(":")[1]), int(c.split(":")[2])) for c in os.environ["PROBE_CASES"].split(",")]
+THRS = [int(t) for t in os.environ.get("PROBE_THR", "10,25,50").split(",")]
+for block, fill, noise in CASES:
     a = block_dense_graph(200_000, block, fill, noise, seed=1)
     B = torch.rand((a.n, k), device="cuda") * 2 - 1
     C = torch.empty((a.m, k), device="cuda")
     v_us, _, ref = timed(a, B, C, {"FLEX_MFMA": 2})
     line = f"block {block} fill {fill} noise {noise}: n={a.n} nnz={a.nnz}  vector {v_us:8.1f} us ({2e-3 * a.nnz * k / v_us:7.0f} GFLOPS)"
-    for thr in (10, 25, 50):
+    for thr in THRS:
         us, info, out = timed(a, B, C, {"FLEX_MFMA": 1, "FLEX_MFMA_FILL": thr})
         err = (out - ref).abs().max().item()
         line += f" | thr {thr}%: {us:8.1f} us ({v_us / us:4.2f}x, {100.0 * info['tile_nnz'] / a.nnz:4.1f}% of nnz in {info['n_tiles']} tiles, |d|={err:.1e})"
