@@ -87,8 +87,8 @@ namespace {
 // FLEX_PLAN_AUTOTUNE: the degree rule picks the column-tile width G from two thresholds measured on a handful of
 // shapes; this measures instead.  The neighbouring widths are planned too (same row schedule, computed once),
 // each candidate is timed on zero-filled operands of the real size (what a gather costs depends on its address,
-// not on the value), and the fastest plan is kept.  Costs two extra plans and 2 * 4*(n*ldb + m*ldc) bytes for the
-// duration of the call.
+// not on the value), and the fastest plan is kept.  Costs up to three extra plans and 2 * 4*(n*ldb + m*ldc) bytes for
+// the duration of the call.
 int autotune(flex_plan **pp, const flex_csr *A, int32_t r0, int32_t r1, const int32_t *col_map, const int32_t *dst_map,
              unsigned flags, const flex_plan_tuning &tuning, std::vector<uint32_t> &sched_cache) {
     flex_plan *best = *pp;
@@ -137,6 +137,28 @@ int autotune(flex_plan **pp, const flex_csr *A, int32_t r0, int32_t r1, const in
         }
         free_plan_device(q);
         delete q;
+    }
+    // Row bundles the same way: their rule is one threshold (a chunk per wave slot of the card) between two measured regimes, so on
+    // the tiles that have them the other setting is planned and timed too, at the width that won above -- unless the caller chose.
+    if (!rc && tuning.bundle == 0 && 64 / best->lanes_per_nz >= static_cast<int>(kBundleMinSlots)) {
+        flex_plan_tuning other = tuning;
+        other.bundle = best->n_bundles ? 2 : 1;
+        flex_plan *q = new (std::nothrow) flex_plan();
+        if (q) {
+            q->m = best->m; q->n = best->n; q->k = best->k; q->device = best->device;
+            q->ldb = best->ldb; q->ldc = best->ldc; q->nnz = best->nnz;
+            double us = 0.0;
+            int rq = build_plan(q, A, r0, r1, col_map, dst_map, flags, other, &sched_cache, best->lanes_per_nz);
+            if (rq == FLEX_OK && hipDeviceSynchronize() != hipSuccess) rq = FLEX_ERR_HIP;
+            if (rq == FLEX_OK && q->lanes_per_nz == best->lanes_per_nz && (q->n_bundles != 0) != (best->n_bundles != 0)) time_plan(q, &us);
+            else rq = FLEX_ERR_UNSUPPORTED;  // nothing to compare (e.g. no row short enough to bundle)
+            if (rq == FLEX_OK && !rc && us < best_us) {
+                std::swap(best, q);
+                best_us = us;
+            }
+            free_plan_device(q);
+            delete q;
+        }
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);

@@ -199,7 +199,7 @@ class PlanBuilder {
             G = std::min(G, force_G);
         } else if (const int g_t = tn.lanes_per_nz; g_t == 8 || g_t == 16 || g_t == 32 || g_t == 64 || (g_t == 4 && narrow_ok)) {
             G = g_t == 4 ? 4 : std::min<int>(G, g_t);  // tuning experiments
-        } else if (narrow_ok && (avg_deg >= 8.0 || tn.bundle == 1 || (tn.bundle != 2 && fills_the_chip()))) {
+        } else if (narrow_ok && (avg_deg >= 8.0 || tn.bundle == 1 || (tn.bundle != 2 && bundle_rule()))) {
             G = 4;
         } else {
             G = std::min(G, 32);  // k = 256 as two 128-column tiles beats one 256-column tile on every shape measured
@@ -209,7 +209,7 @@ class PlanBuilder {
             // the wide tile, and two passes over half-rows of B keep more of them in the L2s (k=128, 32-lane tile without bundles ->
             // 16-lane tile with: epinions stand-in 47.9 -> 46.1 us on 316 -> 300 MB, yelp shape 533 -> 519 us on 3.59 -> 3.22 GB,
             // flickr shape 38.2 -> 38.1; profiles/r04_row_bundles.txt).  The 8-lane tile loses again (48.3 / 560 / 38.6).
-            if (tn.bundle == 1 || (tn.bundle != 2 && fills_the_chip())) G = std::min(G, 16);
+            if (tn.bundle == 1 || (tn.bundle != 2 && bundle_rule())) G = std::min(G, 16);
         }
         S = 64u / static_cast<uint32_t>(G);
         p->lanes_per_nz = G;
@@ -484,7 +484,7 @@ class PlanBuilder {
 
     // Would the plan, cut the usual way, hold at least one chunk for every wave slot of the card (256 CUs x 32)?  Below that a launch is
     // bound by the latency of ONE wave's chain -- header, descriptors, records, gathers, store -- and not by instruction or memory
-    // throughput, and what shortens the chain is MORE lanes per row, not fewer.
+    // throughput.
     bool fills_the_chip() const {
         const double budget = std::clamp(16.0 * avg_deg, 128.0, 512.0);
         return (static_cast<double>(slice_nnz()) + 16.0 * m) / budget >= 8192.0;
@@ -494,11 +494,14 @@ class PlanBuilder {
     //   16.1 -> 12.9, yelp shape (degree 19) 130.5 -> 120.2, reddit shape (degree 50, few short rows) 161.4 -> 160.9;
     //   k=64 (4 slots): 27.3 -> 25.2, 24.3 -> 21.8;  k=16 (16 slots): 18.1 -> 12.2, 14.8 -> 11.6;
     //   wave instructions per 64 multiply-adds on the epinions stand-in at k=32: 10.4 VALU + 10.5 SALU -> 3.9 + 3.7.
-    // Graphs that do not fill the chip LOSE (pubmed.csv k=32 5.14 -> 5.37 us, wiki-Vote shape k=16 5.5 -> 7.3, ppi shape 8.2 -> 8.4):
-    // a bundle walks its rows' records one step after the other where the plain form spreads a row over the slots of one step,
-    // and a launch that short is the length of one wave's chain.  Candidate length: 12-16 records is the optimum on all three tiles
-    // (24-32: +2-7 %, longer chains and more padding inside a bundle); hence 16.
-    bool bundle_rule() const { return fills_the_chip(); }
+    // Candidate length: 12-16 records is the optimum on all three tiles (24-32: +2-7 %, longer chains and more padding inside a
+    // bundle); hence 16.  Graphs that do NOT fill the chip run one wave's chain long, and a bundle walks its rows' records one step
+    // after the other where the plain form spreads a row over the slots of one step: with candidates of up to 32 records bundles
+    // lost there (pubmed.csv k=32 5.14 -> 5.37 us), with 16 they win where the rows are short -- pubmed.csv (degree 5.5) k=16 / 32 /
+    // 64 / 128: 5.10 -> 4.44, 5.17 -> 4.64, 6.68 -> 6.47, 8.14 -> 7.56 us; wiki-Vote shape (degree 12): 5.41 -> 5.56, 5.79 -> 5.80,
+    // 7.05 -> 6.77, 8.31 -> 7.77 -- and lose where few rows are (ppi shape, degree 28: k=32 8.25 -> 8.41, k=128 18.8 -> 20.5).
+    // Hence: on when the plan fills the chip, or the average degree is below 16.
+    bool bundle_rule() const { return fills_the_chip() || avg_deg < 16.0; }
 
     // A run of `len` records as pieces: one, or (longer than a budget) several of about one budget.  The last piece to
     // arrive sums all of them with ONE wave, so a hub of 10^6 nonzeros cut into 10^4 budget-sized pieces spent 0.9 ms

@@ -67,8 +67,9 @@ typedef struct flex_plan flex_plan;
 #define FLEX_PLAN_STATS 0x100u /* also collect flex_plan_stats while planning (one extra pass over the records) */
 #define FLEX_PLAN_AUTOTUNE 0x200u /* measure instead of trusting the degree rule: plan the neighbouring column-tile
                                      widths too (same row schedule), time each on zero-filled operands of the real
-                                     size, keep the fastest.  Costs two extra plans and, for the duration of the call,
-                                     device memory for one B and one C */
+                                     size, keep the fastest; likewise the other setting of tuning.bundle where the tile
+                                     has row bundles and the caller left it to the rule.  Costs up to three extra plans
+                                     and, for the duration of the call, device memory for one B and one C */
 #define FLEX_PLAN_ROW_RANGE 0x1000u /* flex_plan_create_ex only: desc->row_begin/row_end name a row shard */
 #define FLEX_PLAN_XCD_INTERLEAVE 0x2000u /* deal the chunks round-robin over the 8 XCDs instead of giving each XCD one
                                             contiguous eighth of the schedule.  For rows that arrive in a BFS-like order

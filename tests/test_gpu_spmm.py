@@ -503,10 +503,12 @@ def test_plan_stats_reuse_and_imbalance_report():
     # (1) diagonal: no B row is ever reused
     rp = np.arange(n + 1, dtype=np.uint32)
     a = flex_amd.HostCsr(rp, np.arange(n, dtype=np.uint32), np.ones(n, np.float32), n=n)
-    st = Plan(a, 32, order=FLEX_ORDER_NATURAL | FLEX_PLAN_STATS).stats()
+    st = Plan(a, 32, order=FLEX_ORDER_NATURAL | FLEX_PLAN_STATS, tuning={"bundle": 2}).stats()
     assert st["cols_wave"] == st["cols_wg"] == st["cols_xcd"] == n
     assert st["reuse_wave"] == st["reuse_xcd"] == 1.0 and st["split_nnz_pct"] == 0.0
-    assert st["records"] == n * 8 and abs(st["pad_pct"] - 700.0) < 1e-9  # k=32: 8 records per gather step
+    assert st["records"] == n * 8 and abs(st["pad_pct"] - 700.0) < 1e-9  # k=32: 8 records per gather step, a row padded to one
+    st = Plan(a, 32, order=FLEX_ORDER_NATURAL | FLEX_PLAN_STATS).stats()  # the rule: short rows side by side in bundles, nothing to pad
+    assert st["records"] == n and st["pad_pct"] == 0.0 and st["cols_xcd"] == n
     # (2) every row reads the same 16 B rows: one fetch per chunk / workgroup / XCD slice
     deg = 16
     rp = (np.arange(n + 1) * deg).astype(np.uint32)
@@ -726,14 +728,23 @@ def test_narrow_tile_for_k_up_to_16(knobs, k, split_rows):
         assert p8.info()["lanes_per_nz"] == 8
         assert oracle.rescheck(run_plan(p8, B), C4, a.rowPtr)[0] == 0
         knobs.clear("lanes_per_nz")
-    low = random_csr(5000, 5000, 3, seed=102)  # average degree 3: the rule keeps the 8-lane tile, the knob forces the narrow one
+    # average degree 3: without bundles the rule keeps the 8-lane tile (rows are padded to whole steps) and the knob forces the narrow
+    # one; with bundles (the rule for rows this short) nothing is padded and the narrow tile is the rule
+    low = random_csr(5000, 5000, 3, seed=102)
     Bl = random_B(low.n, k, 10)
+    knobs.set(bundle=2)
     assert Plan(low, k).info()["lanes_per_nz"] == 8
     knobs.set(lanes_per_nz=4)
     pl = Plan(low, k)
-    assert pl.info()["lanes_per_nz"] == 4
+    assert pl.info()["lanes_per_nz"] == 4 and pl.info()["n_bundles"] == 0
     pl.self_check()
     assert_matches_oracle(low, Bl, run_plan(pl, Bl))
+    knobs.clear("lanes_per_nz")
+    knobs.clear("bundle")
+    pb = Plan(low, k)
+    assert pb.info()["lanes_per_nz"] == 4 and pb.info()["n_bundles"] > 0
+    assert_matches_oracle(low, Bl, run_plan(pb, Bl))
+    knobs.set(lanes_per_nz=4)
     # wider k ignores the request
     assert Plan(low, 32).info()["lanes_per_nz"] == 8
 
@@ -810,6 +821,16 @@ def test_autotuned_plan_is_correct_and_no_slower_choice_is_kept():
         assert info["lanes_per_nz"] in (8, 16, 32) and st["records"] >= a.nnz
         p.self_check()
         assert_matches_oracle(a, B, run_plan(p, B))
+    # round 4: on the tiles that have row bundles the OTHER bundle setting is planned and timed as well (the rule is one size
+    # threshold); whichever is kept is a valid plan that says what it is, and a caller's own choice is not overridden
+    a = flex_amd.synth_graph(n=60000, nnz=60000 + 2 * 240000, community=128, p_in=0.6, p_near=0.2, seed=82)
+    B = random_B(a.n, 32, 6)
+    p = Plan(a, 32, order=flex_amd.FLEX_ORDER_CLUSTER | FLEX_PLAN_AUTOTUNE)
+    p.self_check()
+    assert p.tuning()["bundle"] == (1 if p.info()["n_bundles"] else 2)
+    assert_matches_oracle(a, B, run_plan(p, B))
+    forced = Plan(a, 32, order=flex_amd.FLEX_ORDER_CLUSTER | FLEX_PLAN_AUTOTUNE, tuning={"bundle": 2})
+    assert forced.info()["n_bundles"] == 0
 
 
 def test_general_entry_point_covers_combinations():

@@ -267,7 +267,8 @@ def test_hot_block_plans_are_partitions(sim, rounds, panel_rows, thr, cap):
         assert i["block_rows"] <= mat.m and i["block_nnz"] <= mat.nnz and i["block_records"] >= i["block_hot_nnz"]
         assert i["block_hot_nnz"] <= i["block_nnz"] and i["block_hot_cols"] <= i["block_panels"] * panel_rows
         assert i["n_records"] >= mat.nnz - i["block_hot_nnz"]  # the flat plan holds exactly the nonzeros the blocks do not (+ padding)
-        assert i["n_tasks"] >= mat.m  # ... and still every row: the flat kernel writes all of C, the hot kernel adds to it
+        # ... and still every row -- as a task of its own or inside a bundle: the flat kernel writes all of C, the hot kernel adds to it
+        assert i["n_tasks"] - i["n_bundles"] + i["bundle_rows"] >= mat.m
         if mat is g and order == flex_amd.FLEX_ORDER_CLUSTER and rounds >= 4 and thr == 2 and panel_rows >= 64:
             assert i["block_hot_nnz"] > 0.3 * mat.nnz  # the planted communities are found as hot columns
     # a row longer than the cap is spread over several slots (parts chained through LDS); with a tiny cap every row is, and rows
@@ -360,21 +361,23 @@ def test_row_bundles_of_rows_without_nonzeros_and_of_one_thread_or_five(sim):
         assert p2.info()["n_bundles"] == 0 and p2.tuning()["bundle"] == 2 and p2.tuning()["bundle_len"] == 0
 
 
-def test_row_bundles_by_rule_only_where_the_plan_fills_the_chip(sim):
+def test_row_bundles_by_rule_where_the_plan_fills_the_chip_or_the_rows_are_short(sim):
     """No knob set: the flickr shape (89 250 rows, degree 11: ~13 000 chunks) gets bundles, on the 16-lane tile from k = 64 up (with
-    bundles it beats the wide tile at low degree too) and on the narrow tile at k = 16 although its degree is below 8; pubmed.csv (19 717 rows, ~5 500 chunks) does not -- a launch that short is
-    one wave's chain long, and a bundle's chain is the longer one (plan_build.cpp, bundle_rule)."""
+    bundles it beats the wide tile at low degree too) and on the narrow tile at k = 16 although its degree is below 8; so does
+    pubmed.csv (19 717 rows of degree 5.5: too few chunks to fill the chip, but its rows are short); a small graph of degree 28
+    (the ppi shape's class) keeps the plain plan (plan_build.cpp, bundle_rule)."""
     fl = flex_amd.synth_graph("flickr")
     pm = flex_amd.csv_load(os.path.join(os.path.dirname(__file__), "golden", "pubmed.csv"))
-    for k, lanes, on in ((16, 4, True), (32, 8, True), (64, 16, True), (128, 16, True), (256, 16, True)):
-        p = flex_amd.Plan(fl, k, order=flex_amd.FLEX_ORDER_CLUSTER)
-        p.self_check()
-        i, t = p.info(), p.tuning()
-        assert i["lanes_per_nz"] == lanes and (i["n_bundles"] > 1000) == on and t["bundle"] == (1 if on else 2), (k, i, t)
-        assert t["bundle_len"] == (16 if on else 0)
-    for k, lanes in ((16, 8), (32, 8), (64, 16), (128, 32)):
-        p = flex_amd.Plan(pm, k)
-        assert p.info()["n_bundles"] == 0 and p.tuning()["bundle"] == 2 and p.info()["lanes_per_nz"] == lanes
+    for g in (fl, pm):
+        for k, lanes in ((16, 4), (32, 8), (64, 16), (128, 16), (256, 16)):
+            p = flex_amd.Plan(g, k, order=flex_amd.FLEX_ORDER_CLUSTER)
+            p.self_check()
+            i, t = p.info(), p.tuning()
+            assert i["lanes_per_nz"] == lanes and i["n_bundles"] > 1000 and t["bundle"] == 1 and t["bundle_len"] == 16, (k, i, t)
+    small_dense = flex_amd.synth_graph(n=20000, nnz=20000 + 2 * 270000, community=200, p_in=0.6, p_near=0.25, seed=4)
+    for k, lanes in ((16, 4), (32, 8), (64, 16), (128, 16)):
+        p = flex_amd.Plan(small_dense, k)
+        assert p.info()["n_bundles"] == 0 and p.tuning()["bundle"] == 2 and p.tuning()["bundle_len"] == 0 and p.info()["lanes_per_nz"] == lanes
     assert flex_amd.Plan(fl, 128, tuning={"bundle": 2}).info()["lanes_per_nz"] == 32  # without bundles the wide tile stays the rule
     off = flex_amd.Plan(fl, 32, tuning={"bundle": 2})
     assert off.info()["n_bundles"] == 0 and off.info()["n_tasks"] > 4 * flex_amd.Plan(fl, 32).info()["n_tasks"]
