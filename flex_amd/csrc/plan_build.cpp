@@ -460,7 +460,7 @@ class PlanBuilder {
         // Row bundles (form_tasks): only on the tiles of 4 or more slots per step (the kernels of the wide tiles have no code for them),
         // and not on 2-D plans (their tasks are runs of a row, not rows)
         bundles_on = !two_d && S >= kBundleMinSlots && m > 0 && (tn.bundle == 1 || (tn.bundle != 2 && bundle_rule()));
-        bundle_len = static_cast<uint32_t>(pick(tn.bundle_len, 16));
+        bundle_len = static_cast<uint32_t>(pick(tn.bundle_len, S >= 8 ? 12 : 16));
         far_window = two_d ? 0u : static_cast<uint32_t>(std::max(0, tn.far_first));  // (2-D pieces are cut by column panel already)
         p->tuning.far_first = static_cast<int32_t>(far_window);
         // what this plan was built with (flex_plan_get_tuning)
@@ -495,7 +495,8 @@ class PlanBuilder {
     //   k=64 (4 slots): 27.3 -> 25.2, 24.3 -> 21.8;  k=16 (16 slots): 18.1 -> 12.2, 14.8 -> 11.6;
     //   wave instructions per 64 multiply-adds on the epinions stand-in at k=32: 10.4 VALU + 10.5 SALU -> 3.9 + 3.7.
     // Candidate length: 12-16 records is the optimum on all three tiles (24-32: +2-7 %, longer chains and more padding inside a
-    // bundle); hence 16.  Graphs that do NOT fill the chip run one wave's chain long, and a bundle walks its rows' records one step
+    // bundle; 8: +0-6 %): 12 on the tiles of 8 and 16 slots (against 16: wiki-Vote shape -5 %, pubmed.csv k=16 -3 %, the rest
+    // within 1 % either way), 16 on the 4-slot tile.  Graphs that do NOT fill the chip run one wave's chain long, and a bundle walks its rows' records one step
     // after the other where the plain form spreads a row over the slots of one step: with candidates of up to 32 records bundles
     // lost there (pubmed.csv k=32 5.14 -> 5.37 us), with 16 they win where the rows are short -- pubmed.csv (degree 5.5) k=16 / 32 /
     // 64 / 128: 5.10 -> 4.44, 5.17 -> 4.64, 6.68 -> 6.47, 8.14 -> 7.56 us; wiki-Vote shape (degree 12): 5.41 -> 5.56, 5.79 -> 5.80,

@@ -315,7 +315,7 @@ def test_row_bundle_plans_are_partitions(sim, k, lanes):
         p.self_check()
         info, t = p.info(), p.tuning()
         slots = 64 // info["lanes_per_nz"]
-        assert t["bundle"] == 1 and t["bundle_len"] == 16 and plain.tuning()["bundle"] == 2 and plain.info()["n_bundles"] == 0
+        assert t["bundle"] == 1 and t["bundle_len"] == (12 if slots >= 8 else 16) and plain.tuning()["bundle"] == 2 and plain.info()["n_bundles"] == 0
         assert info["n_bundles"] > 0 and info["bundle_rows"] >= 2 * info["n_bundles"] and info["bundle_rows"] <= slots * info["n_bundles"]
         assert info["n_tasks"] < plain.info()["n_tasks"] and info["n_split_rows"] == plain.info()["n_split_rows"] > 0
         assert info["n_records"] < plain.info()["n_records"] and info["n_records"] >= a.nnz
@@ -373,11 +373,11 @@ def test_row_bundles_by_rule_where_the_plan_fills_the_chip_or_the_rows_are_short
             p = flex_amd.Plan(g, k, order=flex_amd.FLEX_ORDER_CLUSTER)
             p.self_check()
             i, t = p.info(), p.tuning()
-            assert i["lanes_per_nz"] == lanes and i["n_bundles"] > 1000 and t["bundle"] == 1 and t["bundle_len"] == 16, (k, i, t)
+            assert i["lanes_per_nz"] == lanes and i["n_bundles"] > 1000 and t["bundle"] == 1 and t["bundle_len"] == (12 if lanes <= 8 else 16), (k, i, t)
     small_dense = flex_amd.synth_graph(n=20000, nnz=20000 + 2 * 270000, community=200, p_in=0.6, p_near=0.25, seed=4)
     for k, lanes in ((16, 4), (32, 8), (64, 16), (128, 16)):
         p = flex_amd.Plan(small_dense, k)
         assert p.info()["n_bundles"] == 0 and p.tuning()["bundle"] == 2 and p.tuning()["bundle_len"] == 0 and p.info()["lanes_per_nz"] == lanes
     assert flex_amd.Plan(fl, 128, tuning={"bundle": 2}).info()["lanes_per_nz"] == 32  # without bundles the wide tile stays the rule
     off = flex_amd.Plan(fl, 32, tuning={"bundle": 2})
-    assert off.info()["n_bundles"] == 0 and off.info()["n_tasks"] > 4 * flex_amd.Plan(fl, 32).info()["n_tasks"]
+    assert off.info()["n_bundles"] == 0 and off.info()["n_tasks"] > 3 * flex_amd.Plan(fl, 32).info()["n_tasks"]
