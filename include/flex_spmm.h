@@ -168,8 +168,9 @@ typedef struct flex_plan_tuning {
     int32_t bundle;          /* row bundles: tasks that hold up to 64 / lanes_per_nz SHORT rows side by side, one per record slot -- no
                                 cross-slot reduction and one store per lane at the end instead of a reduction and a store per row
                                 (≙ the reference's narrow kernel giving every thread its own row, flex.cu:81-118): 1 on, 2 off
-                                (rule: on the tiles of 4 or more slots per step -- k <= 64, or lanes_per_nz <= 16 -- when the plan holds a
-                                chunk for every wave slot of the card, or its average degree is below 16; plan_build.cpp, bundle_rule) */
+                                (rule: on when the plan holds a chunk for every wave slot of the card, or its average degree is below 16
+                                -- and then on the tiles of 4 or more slots per step: wider k runs the 16-lane tile instead of the
+                                32-lane one; plan_build.cpp, bundle_rule) */
     int32_t bundle_len;      /* ... rows of at most this many nonzeros are candidates (12 on the tiles of 8 or 16 slots per step, 16 on the 4-slot tile) */
     int32_t reserved[5];     /* zero */
 } flex_plan_tuning;
