@@ -394,8 +394,12 @@ class PlanBuilder {
         // 5.5 us at 128-160 records per chunk, 6.3 at 200)
         // (round 3, pubmed.csv k=32 with no row split: 4.8 us at 48-64 records per chunk, 4.9 at 96, 5.1 at 128, 5.6 at 192 -- on the G = 8
         //  tile a graph this small may go down to 64; k=128 is flat from 64 to 128: profiles/r03_small_graph_sweep.txt)
+        // (round 4, the 16-lane tile with row bundles -- what small graphs of short rows run at k >= 64: 64 records per chunk against
+        //  96: pubmed.csv k=64 6.4 -> 5.6 us, k=128 7.9 -> 7.1; wiki-Vote shape k=64 6.7 -> 6.3, k=128 level;
+        //  profiles/r04_row_bundles.txt)
+        const bool bundles_expected = tn.two_d != 1 && S >= kBundleMinSlots && m > 0 && (tn.bundle == 1 || (tn.bundle != 2 && bundle_rule()));
         const long n_rec = static_cast<long>(A->rowPtr[r1] - A->rowPtr[r0]);
-        auto_budget = std::min(auto_budget, std::max<long>(G <= 8 ? 64 : lo_budget, n_rec / 2048));
+        auto_budget = std::min(auto_budget, std::max<long>(G <= 8 || bundles_expected ? 64 : lo_budget, n_rec / 2048));
         wave_nnz = static_cast<uint32_t>(pick(tn.chunk_records, auto_budget));
         row_cost = static_cast<uint32_t>(pick(tn.row_cost, 16));
         // Contiguous XCD slices (workgroup ids remapped) keep a community's rows on ONE private L2; they pay when the
@@ -459,7 +463,7 @@ class PlanBuilder {
         seg_min = static_cast<uint32_t>(pick(tn.seg_min, 4));
         // Row bundles (form_tasks): only on the tiles of 4 or more slots per step (the kernels of the wide tiles have no code for them),
         // and not on 2-D plans (their tasks are runs of a row, not rows)
-        bundles_on = !two_d && S >= kBundleMinSlots && m > 0 && (tn.bundle == 1 || (tn.bundle != 2 && bundle_rule()));
+        bundles_on = bundles_expected && !two_d;
         bundle_len = static_cast<uint32_t>(pick(tn.bundle_len, S >= 8 ? 12 : 16));
         far_window = two_d ? 0u : static_cast<uint32_t>(std::max(0, tn.far_first));  // (2-D pieces are cut by column panel already)
         p->tuning.far_first = static_cast<int32_t>(far_window);
